@@ -1,0 +1,184 @@
+// GF(2^255-19) for gfx950: 8 x 32-bit saturated limbs, values kept anywhere in [0, 2^256) ("weakly reduced",
+// 2^256 = 38 mod p).  Products go through 64-bit multiply-adds (v_mad_u64_u32); 8 VGPRs per element keeps an
+// extended point at 32 VGPRs.  Replaces curve25519-dalek's FieldElement (not vendored in the reference;
+// Cargo.toml:8) underneath the calls at reference src/bin/prover.rs:53-54,92-93.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BPG_HD __host__ __device__ __forceinline__
+#define BPG_UNROLL _Pragma("unroll")
+#else
+#define BPG_HD inline
+#define BPG_UNROLL
+#endif
+
+namespace bpg {
+
+struct fe { uint32_t v[8]; };
+
+BPG_HD fe fe_zero() { fe r; BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+BPG_HD fe fe_one() { fe r = fe_zero(); r.v[0] = 1; return r; }
+
+// r = lo + 38 * hi for a 512-bit product t[0..15]
+BPG_HD fe fe_fold512(const uint32_t t[16]) {
+    fe r; uint64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) {
+        c += (uint64_t)t[i] + (uint64_t)t[i + 8] * 38u;
+        r.v[i] = (uint32_t)c; c >>= 32;
+    }
+    // c < 39 : fold again
+    uint64_t d = (uint64_t)r.v[0] + c * 38u;
+    r.v[0] = (uint32_t)d; d >>= 32;
+    BPG_UNROLL for (int i = 1; i < 8; i++) { d += r.v[i]; r.v[i] = (uint32_t)d; d >>= 32; }
+    r.v[0] += 38u * (uint32_t)d;      // a second wrap leaves a tiny value: no further carry
+    return r;
+}
+
+BPG_HD fe fe_mul(const fe &a, const fe &b) {
+    uint32_t t[16];
+    BPG_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t carry = 0;
+        BPG_UNROLL for (int j = 0; j < 8; j++) {
+            uint64_t x = (uint64_t)a.v[i] * b.v[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)x; carry = x >> 32;
+        }
+        t[i + 8] = (uint32_t)carry;
+    }
+    return fe_fold512(t);
+}
+
+BPG_HD fe fe_sq(const fe &a) {
+    // off-diagonal products once, doubled, plus the diagonal
+    uint32_t t[16];
+    BPG_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
+    BPG_UNROLL for (int i = 0; i < 7; i++) {
+        uint64_t carry = 0;
+        BPG_UNROLL for (int j = i + 1; j < 8; j++) {
+            uint64_t x = (uint64_t)a.v[i] * a.v[j] + t[i + j] + carry;
+            t[i + j] = (uint32_t)x; carry = x >> 32;
+        }
+        t[i + 8] = (uint32_t)carry;
+    }
+    // double
+    uint32_t top = 0;
+    BPG_UNROLL for (int i = 1; i < 16; i++) { uint32_t n = t[i] >> 31; t[i] = (t[i] << 1) | top; top = n; }
+    // add squares
+    uint64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t s = (uint64_t)a.v[i] * a.v[i];
+        c += (uint64_t)t[2 * i] + (uint32_t)s; t[2 * i] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)t[2 * i + 1] + (s >> 32); t[2 * i + 1] = (uint32_t)c; c >>= 32;
+    }
+    return fe_fold512(t);
+}
+
+BPG_HD fe fe_add(const fe &a, const fe &b) {
+    fe r; uint64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    uint64_t d = (uint64_t)r.v[0] + 38u * c;
+    r.v[0] = (uint32_t)d; d >>= 32;
+    BPG_UNROLL for (int i = 1; i < 8; i++) { d += r.v[i]; r.v[i] = (uint32_t)d; d >>= 32; }
+    r.v[0] += 38u * (uint32_t)d;
+    return r;
+}
+
+BPG_HD fe fe_sub(const fe &a, const fe &b) {
+    fe r; int64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    // c is 0 or -1 : a - b + 2^256 = a - b + 38 (mod p), so take 38 back off
+    int64_t d = (int64_t)r.v[0] + 38 * c;
+    r.v[0] = (uint32_t)d; d >>= 32;
+    BPG_UNROLL for (int i = 1; i < 8; i++) { d += r.v[i]; r.v[i] = (uint32_t)d; d >>= 32; }
+    r.v[0] -= 38u * (uint32_t)(-d);   // second borrow leaves a value just below 2^256: no further borrow
+    return r;
+}
+
+BPG_HD fe fe_neg(const fe &a) { return fe_sub(fe_zero(), a); }
+
+BPG_HD fe fe_mul_small(const fe &a, uint32_t k) {   // k < 2^26
+    fe r; uint64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] * k; r.v[i] = (uint32_t)c; c >>= 32; }
+    uint64_t d = (uint64_t)r.v[0] + c * 38u;     // c < 2^26 : 38c < 2^32
+    r.v[0] = (uint32_t)d; d >>= 32;
+    BPG_UNROLL for (int i = 1; i < 8; i++) { d += r.v[i]; r.v[i] = (uint32_t)d; d >>= 32; }
+    r.v[0] += 38u * (uint32_t)d;
+    return r;
+}
+
+// canonical representative in [0, p)
+BPG_HD fe fe_freeze(const fe &a) {
+    fe r = a;
+    // fold bit 255 twice (value < 2^256 -> < 2^255 + 19 -> < 2^255 + small)
+    BPG_UNROLL for (int k = 0; k < 2; k++) {
+        uint32_t top = r.v[7] >> 31; r.v[7] &= 0x7fffffffu;
+        uint64_t c = (uint64_t)r.v[0] + 19u * top; r.v[0] = (uint32_t)c; c >>= 32;
+        BPG_UNROLL for (int i = 1; i < 8; i++) { c += r.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    }
+    // now r < 2^255; subtract p iff r >= p  <=>  r + 19 >= 2^255
+    fe s; uint64_t c = (uint64_t)r.v[0] + 19u; s.v[0] = (uint32_t)c; c >>= 32;
+    BPG_UNROLL for (int i = 1; i < 8; i++) { c += r.v[i]; s.v[i] = (uint32_t)c; c >>= 32; }
+    uint32_t ge_p = s.v[7] >> 31;
+    s.v[7] &= 0x7fffffffu;
+    uint32_t m = 0u - ge_p;
+    BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = (r.v[i] & ~m) | (s.v[i] & m);
+    return r;
+}
+
+BPG_HD fe fe_frombytes(const uint8_t *s) {   // ignores bit 255, like dalek FieldElement::from_bytes
+    fe r;
+    BPG_UNROLL for (int i = 0; i < 8; i++)
+        r.v[i] = (uint32_t)s[4 * i] | ((uint32_t)s[4 * i + 1] << 8) | ((uint32_t)s[4 * i + 2] << 16) | ((uint32_t)s[4 * i + 3] << 24);
+    r.v[7] &= 0x7fffffffu;
+    return r;
+}
+BPG_HD fe fe_fromwords(const uint32_t *w) { fe r; BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = w[i]; r.v[7] &= 0x7fffffffu; return r; }
+
+BPG_HD void fe_tobytes(uint8_t *s, const fe &a) {
+    fe r = fe_freeze(a);
+    BPG_UNROLL for (int i = 0; i < 8; i++) { s[4 * i] = (uint8_t)r.v[i]; s[4 * i + 1] = (uint8_t)(r.v[i] >> 8); s[4 * i + 2] = (uint8_t)(r.v[i] >> 16); s[4 * i + 3] = (uint8_t)(r.v[i] >> 24); }
+}
+
+BPG_HD uint32_t fe_isnegative(const fe &a) { return fe_freeze(a).v[0] & 1u; }
+BPG_HD uint32_t fe_iszero(const fe &a) { fe r = fe_freeze(a); uint32_t o = 0; BPG_UNROLL for (int i = 0; i < 8; i++) o |= r.v[i]; return o == 0; }
+BPG_HD uint32_t fe_eq(const fe &a, const fe &b) { return fe_iszero(fe_sub(a, b)); }
+BPG_HD fe fe_select(const fe &a, const fe &b, uint32_t pick_b) {   // pick_b in {0,1}
+    uint32_t m = 0u - pick_b; fe r;
+    BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = (a.v[i] & ~m) | (b.v[i] & m);
+    return r;
+}
+BPG_HD fe fe_cneg(const fe &a, uint32_t neg) { return fe_select(a, fe_neg(a), neg); }
+BPG_HD fe fe_abs(const fe &a) { return fe_cneg(a, fe_isnegative(a)); }
+
+BPG_HD fe fe_sqn(fe a, int n) { for (int i = 0; i < n; i++) a = fe_sq(a); return a; }
+
+// z^(2^250-1) and z^11
+BPG_HD void fe_pow22501(fe &t19, fe &t3, const fe &z) {
+    fe t0 = fe_sq(z);
+    fe t1 = fe_sqn(t0, 2);
+    fe t2 = fe_mul(z, t1);
+    t3 = fe_mul(t0, t2);
+    fe t4 = fe_sq(t3);
+    fe t5 = fe_mul(t2, t4);
+    fe t7 = fe_mul(fe_sqn(t5, 5), t5);
+    fe t9 = fe_mul(fe_sqn(t7, 10), t7);
+    fe t11 = fe_mul(fe_sqn(t9, 20), t9);
+    fe t13 = fe_mul(fe_sqn(t11, 10), t7);
+    fe t15 = fe_mul(fe_sqn(t13, 50), t13);
+    fe t17 = fe_mul(fe_sqn(t15, 100), t15);
+    t19 = fe_mul(fe_sqn(t17, 50), t13);
+}
+BPG_HD fe fe_invert(const fe &z) { fe t19, t3; fe_pow22501(t19, t3, z); return fe_mul(fe_sqn(t19, 5), t3); }
+BPG_HD fe fe_pow22523(const fe &z) { fe t19, t3; fe_pow22501(t19, t3, z); return fe_mul(fe_sqn(t19, 2), z); }
+
+#define BPG_FE(w0, w1, w2, w3, w4, w5, w6, w7) fe{{w0, w1, w2, w3, w4, w5, w6, w7}}
+BPG_HD fe FE_D() { return BPG_FE(0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu); }
+BPG_HD fe FE_D2() { return BPG_FE(0x26b2f159u, 0xebd69b94u, 0x8283b156u, 0x00e0149au, 0xeef3d130u, 0x198e80f2u, 0x56dffce7u, 0x2406d9dcu); }
+BPG_HD fe FE_SQRTM1() { return BPG_FE(0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u); }
+BPG_HD fe FE_SQRT_AD_MINUS_ONE() { return BPG_FE(0x497b2e1bu, 0x7e97f6a0u, 0x1b7854bdu, 0xaf9d8e0cu, 0x31f5d1fdu, 0x0f3cfcc9u, 0x2b8348acu, 0x376931bfu); }
+BPG_HD fe FE_INVSQRT_A_MINUS_D() { return BPG_FE(0x805d40eau, 0x99c8fdaau, 0x5a4172beu, 0x9d2f1617u, 0xfe01d840u, 0x16c27b91u, 0xcfaffca2u, 0x786c8905u); }
+BPG_HD fe FE_ONE_MINUS_D_SQ() { return BPG_FE(0x945fc176u, 0xe27c09c1u, 0xcd5e350fu, 0x2c81a138u, 0xbe70dfe4u, 0x9994abddu, 0xb2b3e0d7u, 0x029072a8u); }
+BPG_HD fe FE_D_MINUS_ONE_SQ() { return BPG_FE(0x44ed4d20u, 0x31ad5aaau, 0xb01e1999u, 0xd29e4a2cu, 0x529b4eebu, 0x4cdcd32fu, 0xf66c2241u, 0x5968b37au); }
+
+}  // namespace bpg

@@ -1,0 +1,96 @@
+// Scalars mod l = 2^252 + 27742317777372353535851937790883648493 for gfx950.
+// Device-resident scalar vectors are kept in MONTGOMERY form (x * 2^256 mod l, canonical < l) as 8 x u32, so that
+// the Hadamard / inner-product / fold kernels cost one Montgomery product per multiply.  Conversions happen at the
+// byte boundary (sc_from_bytes / sc_to_words).  Replaces curve25519-dalek Scalar arithmetic (not vendored;
+// reference Cargo.toml:8; semantics per reference src/conversions.rs:18 `Scalar::from_bits`).
+#pragma once
+#include "fe.cuh"
+
+namespace bpg {
+
+struct scm { uint32_t v[8]; };    // Montgomery form
+
+#define BPG_SCM(w0, w1, w2, w3, w4, w5, w6, w7) scm{{w0, w1, w2, w3, w4, w5, w6, w7}}
+BPG_HD scm SC_L() { return BPG_SCM(0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u); }
+BPG_HD scm SC_R1() { return BPG_SCM(0x8d98951du, 0xd6ec3174u, 0x737dcf70u, 0xc6ef5bf4u, 0xfffffffeu, 0xffffffffu, 0xffffffffu, 0x0fffffffu); }   // 1 in Montgomery form
+BPG_HD scm SC_RR() { return BPG_SCM(0x449c0f01u, 0xa40611e3u, 0x68859347u, 0xd00e1ba7u, 0x17f5be65u, 0xceec73d2u, 0x7c309a3du, 0x0399411bu); }
+BPG_HD scm SC_RRR() { return BPG_SCM(0x7b83a2dbu, 0x2a9e4968u, 0xaef7f3ecu, 0x278324e6u, 0x04ec5b65u, 0x8065dc6cu, 0x3599cec7u, 0x0e530b77u); }
+#define BPG_SC_NINV 0x12547e1bu
+
+BPG_HD scm sc_zero() { scm r; BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
+BPG_HD scm sc_plain_one() { scm r = sc_zero(); r.v[0] = 1; return r; }
+
+// t (9 limbs, value < 2l) -> t mod l
+BPG_HD scm sc_cond_sub(const uint32_t t[9]) {
+    const scm L = SC_L();
+    uint32_t s[8]; int64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (int64_t)t[i] - (int64_t)L.v[i]; s[i] = (uint32_t)c; c >>= 32; }
+    c += t[8];                                  // c == -1  <=>  t < l
+    uint32_t keep = (uint32_t)(c >> 63) & 1u;   // 1: keep t
+    uint32_t m = 0u - keep; scm r;
+    BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = (t[i] & m) | (s[i] & ~m);
+    return r;
+}
+
+// Montgomery product a*b/2^256 mod l; needs a*b < 2^256 * l (true when one operand < l); output canonical
+BPG_HD scm sc_mont_mul(const scm &a, const scm &b) {
+    const scm L = SC_L();
+    uint32_t t[10];
+    BPG_UNROLL for (int i = 0; i < 10; i++) t[i] = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) {
+        uint64_t c = 0;
+        BPG_UNROLL for (int j = 0; j < 8; j++) {
+            uint64_t x = (uint64_t)a.v[j] * b.v[i] + t[j] + c;
+            t[j] = (uint32_t)x; c = x >> 32;
+        }
+        uint64_t x = (uint64_t)t[8] + c; t[8] = (uint32_t)x; t[9] = (uint32_t)(x >> 32);
+        uint32_t m = t[0] * BPG_SC_NINV;
+        c = ((uint64_t)m * L.v[0] + t[0]) >> 32;
+        BPG_UNROLL for (int j = 1; j < 4; j++) {
+            uint64_t y = (uint64_t)m * L.v[j] + t[j] + c;
+            t[j - 1] = (uint32_t)y; c = y >> 32;
+        }
+        // limbs 4..6 of l are zero
+        BPG_UNROLL for (int j = 4; j < 7; j++) { uint64_t y = (uint64_t)t[j] + c; t[j - 1] = (uint32_t)y; c = y >> 32; }
+        { uint64_t y = (uint64_t)m * L.v[7] + t[7] + c; t[6] = (uint32_t)y; c = y >> 32; }
+        uint64_t y = (uint64_t)t[8] + c; t[7] = (uint32_t)y;
+        t[8] = t[9] + (uint32_t)(y >> 32); t[9] = 0;
+    }
+    return sc_cond_sub(t);
+}
+
+BPG_HD scm sc_add(const scm &a, const scm &b) {
+    uint32_t t[9]; uint64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; t[i] = (uint32_t)c; c >>= 32; }
+    t[8] = (uint32_t)c;
+    return sc_cond_sub(t);
+}
+
+BPG_HD scm sc_sub(const scm &a, const scm &b) {
+    const scm L = SC_L();
+    scm r; int64_t c = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { c += (int64_t)a.v[i] - (int64_t)b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    uint32_t m = (uint32_t)(c >> 63);           // all ones when a < b
+    uint64_t d = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { d += (uint64_t)r.v[i] + (L.v[i] & m); r.v[i] = (uint32_t)d; d >>= 32; }
+    return r;
+}
+
+BPG_HD scm sc_neg(const scm &a) { return sc_sub(sc_zero(), a); }
+BPG_HD uint32_t sc_iszero(const scm &a) { uint32_t o = 0; BPG_UNROLL for (int i = 0; i < 8; i++) o |= a.v[i]; return o == 0; }
+
+// any 256-bit little-endian integer (8 words) -> Montgomery form of (x mod l)
+BPG_HD scm sc_from_words(const uint32_t *w) { scm x; BPG_UNROLL for (int i = 0; i < 8; i++) x.v[i] = w[i]; return sc_mont_mul(x, SC_RR()); }
+// 512-bit little-endian integer (16 words) -> Montgomery form of (x mod l)   [Scalar::from_bytes_mod_order_wide]
+BPG_HD scm sc_from_wide_words(const uint32_t *w) {
+    scm lo, hi;
+    BPG_UNROLL for (int i = 0; i < 8; i++) { lo.v[i] = w[i]; hi.v[i] = w[8 + i]; }
+    return sc_add(sc_mont_mul(lo, SC_RR()), sc_mont_mul(hi, SC_RRR()));
+}
+// Montgomery form -> canonical integer words
+BPG_HD void sc_to_words(uint32_t *w, const scm &a) {
+    scm r = sc_mont_mul(a, sc_plain_one());
+    BPG_UNROLL for (int i = 0; i < 8; i++) w[i] = r.v[i];
+}
+
+}  // namespace bpg
