@@ -1,0 +1,523 @@
+"""bulletproofs_gadgets_amd - MI355X-native Bulletproofs R1CS prove path behind the reference's Gadget/Prover surface.
+
+Thin ctypes binding of libbpg_hip.so (include/bpg.h).  Names mirror the reference so that its tests translate
+line by line:
+    Transcript, PedersenGens, BulletproofGens, Prover, Verifier          (reference src/bin/prover.rs:47-100)
+    commit, commit_single, commit_all_single, verifier_commit             (src/commitments.rs:8-47)
+    BoundsCheck, MimcHash256, MerkleTree256, Pattern strings, range_proof (src/*/..._gadget.rs, src/utils.rs)
+    be_to_scalar(s), scalar_to_be, mimc_hash                              (src/conversions.rs, src/mimc_hash/mimc.rs)
+All arithmetic happens in the shared library; there is no Python or CPU fallback - importing works without a GPU,
+creating a Context does not.
+"""
+import ctypes as C
+import os
+import pathlib
+
+from . import build as _build
+
+_PKG = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libbpg_hip.so"
+
+FLAG_COMPACT_1PHASE = 1
+FLAG_NO_1PHASE_DOMSEP = 2
+VAR_MULTIPLIER_LEFT, VAR_MULTIPLIER_RIGHT, VAR_MULTIPLIER_OUTPUT, VAR_COMMITTED, VAR_ONE = 0, 1, 2, 3, 4
+L = 2**252 + 27742317777372353535851937790883648493
+
+STATUS_NAMES = {0: "OK", 1: "INVALID_GENERATORS_LENGTH", 2: "FORMAT_ERROR", 3: "VERIFICATION_ERROR", 4: "INVALID_ARGUMENT",
+                5: "MISSING_ASSIGNMENT", 6: "GADGET_ERROR", 7: "DEVICE_ERROR", 8: "INTERNAL"}
+
+
+class BpgError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+class R1CSInstance(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("q", C.c_uint64), ("m", C.c_uint64), ("nnz", C.c_uint64), ("ncoef", C.c_uint64),
+                ("aL", C.c_void_p), ("aR", C.c_void_p), ("aO", C.c_void_p), ("row_ptr", C.c_void_p),
+                ("term_var", C.c_void_p), ("term_coef", C.c_void_p), ("coef", C.c_void_p)]
+
+
+class Timings(C.Structure):
+    _fields_ = [(k, C.c_double) for k in ("rng_host", "msm_aiao", "msm_s", "poly", "ipa", "total", "ipa_msm", "ipa_fold", "ipa_sync")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class _Term(C.Structure):
+    _pack_ = 1
+    _fields_ = [("var", C.c_uint32), ("coeff", C.c_uint8 * 32)]
+
+
+class _LC(C.Structure):
+    _fields_ = [("terms", C.POINTER(_Term)), ("n", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Load (building first if the sources are newer) the shared library."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists() or (os.environ.get("BPG_REBUILD") and _build.needs_build()):
+            _build.build()
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.bpg_strerror.restype = C.c_char_p
+        _lib.bpg_last_error.restype = C.c_char_p
+        for name in ("bpg_proof_size", "bpg_prover_num_constraints", "bpg_prover_num_multiplications", "bpg_prover_num_committed",
+                     "bpg_verifier_num_vars"):
+            getattr(_lib, name).restype = C.c_uint64
+        _lib.bpg_proof_size.argtypes = [C.c_uint64, C.c_uint32]
+    return _lib
+
+
+def _chk(status):
+    if status != 0:
+        raise BpgError(status, lib().bpg_last_error().decode())
+
+
+def _buf(n):
+    return C.create_string_buffer(max(n, 1))
+
+
+# ------------------------------------------------------------------------------------------------ scalars / conversions
+def scalar_from_int(x):
+    return (x % L).to_bytes(32, "little")
+
+
+def be_to_scalars(data: bytes):
+    """conversions::be_to_scalars (src/conversions.rs:26-30): list of 32-byte little-endian Scalar encodings."""
+    n = C.c_uint64(len(data) // 32 + 2)
+    out = _buf(32 * n.value)
+    _chk(lib().bpg_be_to_scalars(bytes(data), C.c_uint64(len(data)), out, C.byref(n)))
+    return [out.raw[32 * i:32 * i + 32] for i in range(n.value)]
+
+
+def be_to_scalar(data: bytes):
+    """conversions::be_to_scalar (src/conversions.rs:49-53)."""
+    if len(data) > 32:
+        raise ValueError("the given vector is longer than 32 bytes")
+    b = bytes(reversed(data)) + bytes(32 - len(data))
+    return b[:31] + bytes([b[31] & 0x7f])
+
+
+def scalar_to_be(s: bytes):
+    return bytes(reversed(s))
+
+
+def mimc_hash(preimage: bytes):
+    """mimc::mimc_hash (src/mimc_hash/mimc.rs:61-75) -> Scalar bytes (little-endian)."""
+    out = _buf(32)
+    _chk(lib().bpg_mimc_hash(bytes(preimage), C.c_uint64(len(preimage)), out))
+    return out.raw
+
+
+def scalar_op(op, a, b=None):
+    out = _buf(32)
+    _chk(lib().bpg_scalar_op(C.c_int32({"add": 0, "sub": 1, "mul": 2, "invert": 3, "reduce": 4, "from_wide": 5}[op]), a, b, out))
+    return out.raw
+
+
+# ------------------------------------------------------------------------------------------------ variables / LCs
+class Variable(int):
+    """bulletproofs::r1cs::Variable packed as kind << 29 | index."""
+    @property
+    def kind(self): return int(self) >> 29
+    @property
+    def index(self): return int(self) & 0x1fffffff
+    @staticmethod
+    def One(): return Variable(VAR_ONE << 29)
+
+
+class LinearCombination:
+    """List of (Variable, Scalar bytes) terms; From<Variable>, From<Scalar>, +, -, * Scalar as upstream."""
+
+    def __init__(self, terms=None):
+        self.terms = list(terms or [])
+
+    @staticmethod
+    def of(x):
+        if isinstance(x, LinearCombination):
+            return x
+        if isinstance(x, Variable):
+            return LinearCombination([(x, scalar_from_int(1))])
+        if isinstance(x, (bytes, bytearray)):
+            return LinearCombination([(Variable.One(), bytes(x))])
+        if isinstance(x, int):
+            return LinearCombination([(Variable.One(), scalar_from_int(x))])
+        raise TypeError(type(x))
+
+    def __add__(self, o): return LinearCombination(self.terms + LinearCombination.of(o).terms)
+    def __sub__(self, o): return LinearCombination(self.terms + [(v, scalar_op("sub", bytes(32), c)) for v, c in LinearCombination.of(o).terms])
+    def __neg__(self): return LinearCombination([(v, scalar_op("sub", bytes(32), c)) for v, c in self.terms])
+    def __mul__(self, s): return LinearCombination([(v, scalar_op("mul", c, s)) for v, c in self.terms])
+
+    def _c(self):
+        arr = (_Term * max(len(self.terms), 1))()
+        for i, (v, c) in enumerate(self.terms):
+            arr[i].var = int(v)
+            arr[i].coeff[:] = c
+        lc = _LC(C.cast(arr, C.POINTER(_Term)), len(self.terms))
+        lc._keep = arr
+        return lc
+
+
+def vars_to_lc(variables):
+    return [LinearCombination.of(v) for v in variables]
+
+
+def _lc_array(lcs):
+    cs = [LinearCombination.of(x)._c() for x in lcs]
+    arr = (_LC * max(len(cs), 1))(*cs)
+    arr._keep = cs
+    return arr
+
+
+# ------------------------------------------------------------------------------------------------ context / generators
+class Context:
+    """One GPU: PedersenGens (fixed bases) + the BulletproofGens tables resident in HBM."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        _chk(lib().bpg_ctx_create(C.c_int32(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bpg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def pedersen_bases(self):
+        a, b = _buf(32), _buf(32)
+        _chk(lib().bpg_pedersen_bases(self._h, a, b))
+        return a.raw, b.raw
+
+    def gens_ensure(self, capacity):
+        _chk(lib().bpg_gens_ensure(self._h, C.c_uint64(capacity)))
+
+    def gens_export(self, first, count):
+        g, h = _buf(32 * count), _buf(32 * count)
+        _chk(lib().bpg_gens_export(self._h, C.c_uint64(first), C.c_uint64(count), g, h))
+        return g.raw[:32 * count], h.raw[:32 * count]
+
+    def pedersen_commit(self, values, blindings):
+        k = len(values)
+        out = _buf(32 * k)
+        _chk(lib().bpg_pedersen_commit(self._h, C.c_uint64(k), b"".join(values), b"".join(blindings), out))
+        return [out.raw[32 * i:32 * i + 32] for i in range(k)]
+
+    def msm_gens(self, first, s, t):
+        out = _buf(32)
+        _chk(lib().bpg_msm_gens(self._h, C.c_uint64(first), C.c_uint64(len(s)), b"".join(s), b"".join(t), out))
+        return out.raw
+
+    # ---- PART 1 boundary on flattened instances
+    def upload(self, inst: "FlatInstance"):
+        h = C.c_void_p()
+        cs = inst.cstruct()
+        _chk(lib().bpg_r1cs_upload(self._h, C.byref(cs), C.byref(h)))
+        return ResidentCircuit(self, h, inst.n, inst.m)
+
+    def prove_flat(self, inst: "FlatInstance", transcript_state, v_blinding, rng_seed, flags=0):
+        ts = _buf(203); ts.raw = bytes(transcript_state)
+        cap = lib().bpg_proof_size(inst.n, flags)
+        out = _buf(cap); ln = C.c_uint64(cap)
+        cs = inst.cstruct()
+        _chk(lib().bpg_r1cs_prove(self._h, C.byref(cs), ts, C.c_uint64(inst.m), v_blinding, rng_seed, C.c_uint32(flags), out, C.byref(ln)))
+        return out.raw[:ln.value], ts.raw[:203]
+
+
+class ResidentCircuit:
+    def __init__(self, ctx, h, n, m):
+        self.ctx, self._h, self.n, self.m = ctx, h, n, m
+
+    def prove(self, transcript_state, v_blinding, rng_seed, flags=0, timings=False):
+        ts = _buf(203); ts.raw = bytes(transcript_state)
+        cap = lib().bpg_proof_size(self.n, flags)
+        out = _buf(cap); ln = C.c_uint64(cap)
+        tm = Timings()
+        _chk(lib().bpg_r1cs_prove_resident(self.ctx._h, self._h, ts, C.c_uint64(self.m), v_blinding, rng_seed, C.c_uint32(flags),
+                                           out, C.byref(ln), C.byref(tm) if timings else None))
+        return (out.raw[:ln.value], ts.raw[:203], tm.as_dict()) if timings else (out.raw[:ln.value], ts.raw[:203])
+
+    def free(self):
+        if self._h:
+            lib().bpg_r1cs_free(self.ctx._h, self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class FlatInstance:
+    """Owned copy of a bpg_r1cs_instance (numpy arrays + bytes); also what tests hand to the oracle."""
+
+    def __init__(self, view: R1CSInstance, v=None, v_blinding=None, commitments=None):
+        import numpy as np
+        self.n, self.q, self.m, self.nnz, self.ncoef = view.n, view.q, view.m, view.nnz, view.ncoef
+        def grab(ptr, nbytes): return C.string_at(ptr, nbytes) if ptr and nbytes else b""
+        self.aL, self.aR, self.aO = grab(view.aL, 32 * self.n), grab(view.aR, 32 * self.n), grab(view.aO, 32 * self.n)
+        self.row_ptr = np.frombuffer(grab(view.row_ptr, 8 * (self.q + 1)), dtype=np.uint64).copy()
+        self.term_var = np.frombuffer(grab(view.term_var, 4 * self.nnz), dtype=np.uint32).copy()
+        self.term_coef = np.frombuffer(grab(view.term_coef, 4 * self.nnz), dtype=np.uint32).copy()
+        self.coef = grab(view.coef, 32 * self.ncoef)
+        self.v, self.v_blinding, self.commitments = v, v_blinding, commitments
+
+    def cstruct(self):
+        c = R1CSInstance()
+        c.n, c.q, c.m, c.nnz, c.ncoef = self.n, self.q, self.m, self.nnz, self.ncoef
+        self._keep = [C.create_string_buffer(x, max(len(x), 1)) for x in (self.aL, self.aR, self.aO, self.coef)]
+        c.aL, c.aR, c.aO, c.coef = [C.cast(k, C.c_void_p).value for k in self._keep]
+        c.row_ptr, c.term_var, c.term_coef = self.row_ptr.ctypes.data, self.term_var.ctypes.data, self.term_coef.ctypes.data
+        return c
+
+
+# ------------------------------------------------------------------------------------------------ transcript / prover / verifier
+class Transcript:
+    """merlin::Transcript::new(label)."""
+
+    def __init__(self, label: bytes):
+        self._h = C.c_void_p()
+        _chk(lib().bpg_transcript_new(bytes(label), C.c_uint64(len(label)), C.byref(self._h)))
+
+    def append_message(self, label: bytes, msg: bytes):
+        _chk(lib().bpg_transcript_append_message(self._h, label, bytes(msg), C.c_uint64(len(msg))))
+
+    def challenge_bytes(self, label: bytes, n: int):
+        out = _buf(n)
+        _chk(lib().bpg_transcript_challenge_bytes(self._h, label, out, C.c_uint64(n)))
+        return out.raw[:n]
+
+    @property
+    def state(self):
+        out = _buf(203)
+        _chk(lib().bpg_transcript_state(self._h, out))
+        return out.raw[:203]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bpg_transcript_free(self._h)
+            self._h = None
+
+
+class Prover:
+    """bulletproofs::r1cs::Prover::new(&pc_gens, &mut transcript)."""
+
+    def __init__(self, ctx: Context, transcript: Transcript):
+        self.ctx, self.transcript = ctx, transcript
+        self._h = C.c_void_p()
+        # ctx=None gives an assembly-only prover (no commitments, no prove) - used by the CPU tests of the host logic
+        _chk(lib().bpg_prover_new(ctx._h if ctx is not None else None, transcript._h, C.byref(self._h)))
+
+    def commit(self, v: bytes, v_blinding: bytes):
+        """Prover::commit(v, v_blinding) -> (CompressedRistretto, Variable)."""
+        com, var = _buf(32), C.c_uint32()
+        _chk(lib().bpg_prover_commit(self._h, v, v_blinding, com, C.byref(var)))
+        return com.raw, Variable(var.value)
+
+    def commit_many(self, vs, blindings):
+        k = len(vs)
+        coms, vars_ = _buf(32 * k), (C.c_uint32 * max(k, 1))()
+        _chk(lib().bpg_prover_commit_many(self._h, C.c_uint64(k), b"".join(vs), b"".join(blindings), coms, vars_))
+        return [coms.raw[32 * i:32 * i + 32] for i in range(k)], [Variable(vars_[i]) for i in range(k)]
+
+    def multiply(self, left, right):
+        out = (C.c_uint32 * 3)()
+        l, r = LinearCombination.of(left)._c(), LinearCombination.of(right)._c()
+        _chk(lib().bpg_prover_multiply(self._h, C.byref(l), C.byref(r), out))
+        return Variable(out[0]), Variable(out[1]), Variable(out[2])
+
+    def allocate_multiplier(self, assignment):
+        out = (C.c_uint32 * 3)()
+        if assignment is None:
+            _chk(lib().bpg_prover_allocate_multiplier(self._h, C.c_int32(0), None, None, out))
+        else:
+            _chk(lib().bpg_prover_allocate_multiplier(self._h, C.c_int32(1), assignment[0], assignment[1], out))
+        return Variable(out[0]), Variable(out[1]), Variable(out[2])
+
+    def allocate(self, assignment):
+        out = C.c_uint32()
+        _chk(lib().bpg_prover_allocate(self._h, C.c_int32(0 if assignment is None else 1), assignment, C.byref(out)))
+        return Variable(out.value)
+
+    def constrain(self, lc):
+        c = LinearCombination.of(lc)._c()
+        _chk(lib().bpg_prover_constrain(self._h, C.byref(c)))
+
+    def num_constraints(self): return lib().bpg_prover_num_constraints(self._h)
+    def get_num_multiplications(self): return lib().bpg_prover_num_multiplications(self._h)
+    def num_committed(self): return lib().bpg_prover_num_committed(self._h)
+
+    def instance(self) -> FlatInstance:
+        view, v, vb = R1CSInstance(), C.c_void_p(), C.c_void_p()
+        _chk(lib().bpg_prover_instance(self._h, C.byref(view), C.byref(v), C.byref(vb)))
+        m = view.m
+        return FlatInstance(view, v=C.string_at(v, 32 * m) if m else b"", v_blinding=C.string_at(vb, 32 * m) if m else b"")
+
+    def prove(self, bp_gens, rng_seed: bytes = bytes(32), flags: int = 0):
+        """Prover::prove(&bp_gens) -> R1CSProof::to_bytes(); rng_seed stands in for thread_rng()."""
+        capacity = bp_gens.gens_capacity if isinstance(bp_gens, BulletproofGens) else int(bp_gens)
+        cap = lib().bpg_proof_size(self.get_num_multiplications(), flags)
+        out = _buf(cap); ln = C.c_uint64(cap)
+        _chk(lib().bpg_prover_prove(self._h, C.c_uint64(capacity), rng_seed, C.c_uint32(flags), out, C.byref(ln), None))
+        return out.raw[:ln.value]
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bpg_prover_free(self._h)
+            self._h = None
+
+
+class Verifier:
+    """bulletproofs::r1cs::Verifier::new(&mut transcript): assembly side only (verification equation: oracle / next round)."""
+
+    def __init__(self, transcript: Transcript):
+        self.transcript = transcript
+        self._h = C.c_void_p()
+        _chk(lib().bpg_verifier_new(transcript._h, C.byref(self._h)))
+
+    def commit(self, com: bytes):
+        var = C.c_uint32()
+        _chk(lib().bpg_verifier_commit(self._h, com, C.byref(var)))
+        return Variable(var.value)
+
+    def get_num_vars(self): return lib().bpg_verifier_num_vars(self._h)
+
+    def instance(self) -> FlatInstance:
+        view, coms = R1CSInstance(), C.c_void_p()
+        _chk(lib().bpg_verifier_instance(self._h, C.byref(view), C.byref(coms)))
+        return FlatInstance(view, commitments=C.string_at(coms, 32 * view.m) if view.m else b"")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bpg_verifier_free(self._h)
+            self._h = None
+
+
+class PedersenGens:
+    """PedersenGens::default() - the bases live in the Context."""
+    def __init__(self, ctx: Context): self.ctx = ctx
+    def bases(self): return self.ctx.pedersen_bases()
+
+
+class BulletproofGens:
+    """BulletproofGens::new(gens_capacity, 1): derives the tables on the GPU and keeps them in HBM."""
+    def __init__(self, ctx: Context, gens_capacity: int, party_capacity: int = 1):
+        if party_capacity != 1:
+            raise ValueError("only party_capacity = 1 is used by the reference (src/bin/prover.rs:92)")
+        self.ctx, self.gens_capacity = ctx, gens_capacity
+        ctx.gens_ensure(gens_capacity)
+
+
+# ------------------------------------------------------------------------------------------------ commitments.rs
+def commit_single(prover: Prover, witness: bytes, blinding: bytes):
+    """commitments::commit_single (src/commitments.rs:22-30)."""
+    assert len(witness) <= 32, "the provided witness is longer than 32 bytes"
+    s = be_to_scalar(witness)
+    com, var = prover.commit(s, blinding)
+    return s, com, var
+
+
+def commit(prover: Prover, witness: bytes, blindings):
+    """commitments::commit (src/commitments.rs:34-43): splits into 32-byte scalars."""
+    scalars = be_to_scalars(witness)
+    coms, vars_ = prover.commit_many(scalars, list(blindings)[:len(scalars)])
+    return scalars, coms, vars_
+
+
+def commit_all_single(prover: Prover, witnesses, blindings):
+    """commitments::commit_all_single (src/commitments.rs:8-19), batched into one kernel launch."""
+    scalars = [be_to_scalar(w) for w in witnesses]
+    coms, vars_ = prover.commit_many(scalars, list(blindings)[:len(scalars)])
+    return scalars, coms, vars_
+
+
+def verifier_commit(verifier: Verifier, commitments):
+    return [verifier.commit(c) for c in commitments]
+
+
+# ------------------------------------------------------------------------------------------------ gadgets
+class Gadget:
+    def __init__(self, handle): self._h = handle
+
+    def setup(self, prover: Prover, witnesses, blindings):
+        """Gadget::setup (src/gadget.rs:18-38) -> (commitments, [(scalar, Variable)])."""
+        cap = 8
+        n = C.c_uint64(cap)
+        coms, dsc, dvars = _buf(32 * cap), _buf(32 * cap), (C.c_uint32 * cap)()
+        _chk(lib().bpg_gadget_setup(self._h, prover._h, b"".join(witnesses), C.c_uint64(len(witnesses)), b"".join(blindings),
+                                    C.c_uint64(len(blindings)), coms, dsc, dvars, C.byref(n)))
+        k = n.value
+        return [coms.raw[32 * i:32 * i + 32] for i in range(k)], [(dsc.raw[32 * i:32 * i + 32], Variable(dvars[i])) for i in range(k)]
+
+    def prove(self, prover: Prover, commitment_vars, derived_witnesses):
+        v = (C.c_uint32 * max(len(commitment_vars), 1))(*[int(x) for x in commitment_vars])
+        dv = (C.c_uint32 * max(len(derived_witnesses), 1))(*[int(x[1]) for x in derived_witnesses])
+        _chk(lib().bpg_gadget_prove(self._h, prover._h, v, C.c_uint64(len(commitment_vars)), b"".join(x[0] for x in derived_witnesses),
+                                    dv, C.c_uint64(len(derived_witnesses))))
+
+    def verify(self, verifier: Verifier, witnesses, derived):
+        v = (C.c_uint32 * max(len(witnesses), 1))(*[int(x) for x in witnesses])
+        dv = (C.c_uint32 * max(len(derived), 1))(*[int(x) for x in derived])
+        _chk(lib().bpg_gadget_verify(self._h, verifier._h, v, C.c_uint64(len(witnesses)), dv, C.c_uint64(len(derived))))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bpg_gadget_free(self._h)
+            self._h = None
+
+
+class BoundsCheck(Gadget):
+    """BoundsCheck::new(&min, &max) (src/bounds_check/bounds_check_gadget.rs:54-63); big-endian byte vectors."""
+    def __init__(self, min_be: bytes, max_be: bytes):
+        h = C.c_void_p()
+        _chk(lib().bpg_bounds_check_new(bytes(min_be), C.c_uint64(len(min_be)), bytes(max_be), C.c_uint64(len(max_be)), C.byref(h)))
+        super().__init__(h)
+
+
+class MimcHash256(Gadget):
+    """MimcHash256::new(image) (src/mimc_hash/mimc_hash_gadget.rs:65-70)."""
+    def __init__(self, image):
+        h = C.c_void_p()
+        lc = LinearCombination.of(image)._c()
+        _chk(lib().bpg_mimc_hash256_new(C.byref(lc), C.byref(h)))
+        super().__init__(h)
+
+
+class MerkleTree256(Gadget):
+    """MerkleTree256::new(root, instance_vars, witness_vars, pattern) (src/merkle_tree/merkle_tree_gadget.rs:59-73).
+    pattern: the tree in the .gadgets syntax with W / I leaves, e.g. "((W W) (I W))"."""
+    def __init__(self, root, instance_vars, witness_vars, pattern: str):
+        h = C.c_void_p()
+        r = LinearCombination.of(root)._c()
+        iv, wv = _lc_array(instance_vars), _lc_array(witness_vars)
+        _chk(lib().bpg_merkle_tree256_new(C.byref(r), iv, C.c_uint64(len(instance_vars)), wv, C.c_uint64(len(witness_vars)),
+                                          pattern.encode(), C.byref(h)))
+        super().__init__(h)
+
+
+def range_proof(cs, x, n_bits, x_assignment=None):
+    """utils::range_proof (src/utils.rs:5-35) on a Prover (assignment given) or a Verifier (None)."""
+    lc = LinearCombination.of(x)._c()
+    if isinstance(cs, Prover):
+        if x_assignment is None:
+            raise BpgError(5, "missing assignment")
+        _chk(lib().bpg_range_proof_prove(cs._h, C.byref(lc), C.c_uint32(n_bits), x_assignment))
+    else:
+        _chk(lib().bpg_range_proof_verify(cs._h, C.byref(lc), C.c_uint32(n_bits)))
+
+
+def hash_pattern(left, right):
+    """hash!(l, r) macro of the reference (merkle_tree_gadget.rs:7-12) on pattern strings."""
+    return "(%s %s)" % (left, right)

@@ -1,0 +1,544 @@
+// Engine implementation: device buffers, generator derivation, the bucket-method MSM pipeline and the prove
+// pipeline (dalek bulletproofs r1cs/prover.rs::prove + inner_product_proof.rs::create re-designed for one GPU;
+// reference call site src/bin/prover.rs:92-93).  Fiat-Shamir stays on the host (merlin.hpp); every challenge is a
+// 32..96-byte device->host copy followed by a few hundred bytes host->device.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include "engine.hpp"
+#include "hip/kernels.cuh"
+
+namespace bpg {
+
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIPCHK(hipFree(p));
+        p = nullptr; cap = 0;
+        HIPCHK(hipMalloc(&p, bytes)); cap = bytes;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    void ensure(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIPCHK(hipHostFree(p));
+        p = nullptr; cap = 0;
+        HIPCHK(hipHostMalloc(&p, bytes, hipHostMallocDefault)); cap = bytes;
+    }
+    void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// host Scalar (plain, canonical) <-> device Montgomery form
+const Scalar &R1_plain() { static Scalar r = [] { Scalar s; s.w[0] = 0xd6ec31748d98951dULL; s.w[1] = 0xc6ef5bf4737dcf70ULL; s.w[2] = 0xfffffffffffffffeULL; s.w[3] = 0x0fffffffffffffffULL; return s; }(); return r; }
+const Scalar &Rinv_plain() { static Scalar r = R1_plain().invert(); return r; }
+scm to_scm(const Scalar &s) { Scalar m = s * R1_plain(); scm o; std::memcpy(o.v, m.w, 32); return o; }
+Scalar from_scm(const scm &m) { Scalar s; std::memcpy(s.w, m.v, 32); return s * Rinv_plain(); }
+
+// non-adjacent form of a canonical scalar; returns index of the top non-zero digit (-1 for zero)
+int32_t naf256(const Scalar &s, int8_t d[256]) {
+    uint64_t k[5] = {s.w[0], s.w[1], s.w[2], s.w[3], 0};
+    std::memset(d, 0, 256);
+    int32_t top = -1;
+    for (int i = 0; i < 256; i++) {
+        if ((k[0] | k[1] | k[2] | k[3] | k[4]) == 0) break;
+        if (k[0] & 1) {
+            int dig = 2 - (int)(k[0] & 3);           // +1 or -1
+            d[i] = (int8_t)dig; top = i;
+            if (dig == 1) k[0] -= 1;                  // low bit set, no borrow
+            else { for (int j = 0; j < 5; j++) { if (++k[j] != 0) break; } }
+        }
+        for (int j = 0; j < 4; j++) k[j] = (k[j] >> 1) | (k[j + 1] << 63);
+        k[4] >>= 1;
+    }
+    return top;
+}
+
+uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; return l; }
+
+}  // namespace
+
+struct DeviceCircuit {
+    uint64_t n = 0, m = 0, q = 0, ncols = 0, nnz = 0;
+    DevBuf aL, aR, aO, col_ptr, ent_row, ent_coef, coef;
+};
+
+struct Engine::Impl {
+    hipStream_t st = nullptr;
+    DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
+    // MSM workspace
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result;
+    // prove buffers
+    DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
+    DevBuf ipa_s, ipa_tabA, ipa_tabB, naf;
+    PinBuf h_raw, h_small;
+    uint64_t gens_cap = 0;
+
+    void msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result);
+};
+
+Engine::Engine(int device) : device_(device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available: the bpg engine has no CPU path");
+    if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
+    HIPCHK(hipSetDevice(device));
+    impl_ = new Impl();
+    HIPCHK(hipStreamCreate(&impl_->st));
+    stream_ = impl_->st;
+    // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
+    static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
+                                   0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+    uint8_t h[64]; sha3_512_host(h, Bc, 32);
+    impl_->small_in.ensure(4096); impl_->bases.ensure(3 * sizeof(ge_niels));
+    HIPCHK(hipMemcpyAsync(impl_->small_in.p, h, 64, hipMemcpyHostToDevice, impl_->st));
+    hipLaunchKernelGGL(k_init_bases, dim3(1), dim3(64), 0, impl_->st, impl_->small_in.as<uint32_t>(), impl_->bases.as<ge_niels>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(impl_->st));
+}
+
+Engine::~Engine() {
+    if (!impl_) return;
+    (void)hipSetDevice(device_);
+    (void)hipStreamSynchronize(impl_->st);
+    DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
+                      &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
+                      &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf};
+    for (DevBuf *b : bufs) b->release();
+    impl_->h_raw.release(); impl_->h_small.release();
+    (void)hipStreamDestroy(impl_->st);
+    delete impl_;
+}
+
+void Engine::synchronize() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(impl_->st)); }
+
+// ------------------------------------------------------------------------------------------------ generators
+void Engine::gens_ensure(uint64_t capacity) {
+    if (capacity == 0 || (capacity & (capacity - 1))) throw std::invalid_argument("generator capacity must be a power of two");
+    if (capacity > (1ULL << 24)) throw std::invalid_argument("generator capacity above 2^24 is not supported");
+    if (capacity <= gens_cap_) return;
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    // GeneratorsChain: SHAKE256("GeneratorsChain" || 'G'|'H' || u32le(party = 0)), 64 bytes per generator (host squeeze,
+    // a serial XOF), then 2*capacity Elligator maps + one batched normalisation on the device.
+    const uint64_t cap = capacity;
+    I.h_raw.ensure(2 * cap * 64);
+    for (int which = 0; which < 2; which++) {
+        Shake256 sh;
+        const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
+        sh.absorb(reinterpret_cast<const uint8_t *>("GeneratorsChain"), 15);
+        sh.absorb(label, 5);
+        sh.squeeze(I.h_raw.as<uint8_t>() + (size_t)which * cap * 64, cap * 64);
+    }
+    I.raw_rng.ensure(2 * cap * 64);
+    I.scratch_ext.ensure(2 * cap * sizeof(ge_ext));
+    DevBuf fresh; fresh.ensure(2 * cap * sizeof(ge_niels));
+    HIPCHK(hipMemcpyAsync(I.raw_rng.p, I.h_raw.p, 2 * cap * 64, hipMemcpyHostToDevice, I.st));
+    const uint32_t cnt = (uint32_t)(2 * cap);
+    hipLaunchKernelGGL(k_gens_derive, dim3(cdiv(cnt, 256)), dim3(256), 0, I.st, I.raw_rng.as<uint32_t>(), I.scratch_ext.as<ge_ext>(), cnt);
+    hipLaunchKernelGGL(k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), 0, I.st, I.scratch_ext.as<ge_ext>(), fresh.as<ge_niels>(), cnt);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(I.st));
+    I.gens.release();
+    I.gens = fresh;
+    gens_cap_ = I.gens_cap = cap;
+}
+
+void Engine::gens_export(uint64_t first, uint64_t count, uint8_t *G_out, uint8_t *H_out) {
+    if (first + count > gens_cap_) throw std::invalid_argument("gens_export: range beyond capacity");
+    if (!count) return;
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    I.comp.ensure(count * 32);
+    for (int which = 0; which < 2; which++) {
+        const ge_niels *src = I.gens.as<ge_niels>() + (which ? gens_cap_ : 0) + first;
+        hipLaunchKernelGGL(k_compress_niels, dim3(cdiv(count, 64)), dim3(64), 0, I.st, src, I.comp.as<uint8_t>(), (uint32_t)count);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(which ? H_out : G_out, I.comp.p, count * 32, hipMemcpyDeviceToHost, I.st));
+        HIPCHK(hipStreamSynchronize(I.st));
+    }
+}
+
+void Engine::pedersen_bases(uint8_t B[32], uint8_t Bb[32]) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    I.comp.ensure(64);
+    hipLaunchKernelGGL(k_compress_niels, dim3(1), dim3(64), 0, I.st, I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), 2u);
+    HIPCHK(hipGetLastError());
+    uint8_t out[64];
+    HIPCHK(hipMemcpyAsync(out, I.comp.p, 64, hipMemcpyDeviceToHost, I.st));
+    HIPCHK(hipStreamSynchronize(I.st));
+    std::memcpy(B, out, 32); std::memcpy(Bb, out + 32, 32);
+}
+
+void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, uint8_t *out) {
+    if (!k) return;
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    // v: keep the caller's 255-bit integer (from_bits semantics); blind: reduce on the host so that bit 255 never matters
+    std::vector<uint8_t> hv(k * 32), hr(k * 32);
+    for (size_t i = 0; i < k; i++) {
+        Scalar a = Scalar::from_bits(v + 32 * i); a.to_bytes(&hv[32 * i]);
+        Scalar b = Scalar::from_bytes_mod_order(blind + 32 * i); b.to_bytes(&hr[32 * i]);
+    }
+    I.small_sc.ensure(2 * k * 32); I.comp.ensure(k * 32);
+    HIPCHK(hipMemcpyAsync(I.small_sc.p, hv.data(), k * 32, hipMemcpyHostToDevice, I.st));
+    HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + k * 32, hr.data(), k * 32, hipMemcpyHostToDevice, I.st));
+    hipLaunchKernelGGL(k_pedersen, dim3(cdiv(k, 64)), dim3(64), 0, I.st, I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + k * 8,
+                       I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), (uint32_t)k);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, I.comp.p, k * 32, hipMemcpyDeviceToHost, I.st));
+    HIPCHK(hipStreamSynchronize(I.st));
+}
+
+// ------------------------------------------------------------------------------------------------ MSM pipeline
+void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
+    const uint32_t total = S.start[S.nseg];
+    uint32_t per = total / (nmsm ? nmsm : 1); if (per < 1) per = 1;
+    int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > 16) cc = 16;
+    const uint32_t c = (uint32_t)cc, W = (254 + c - 1) / c, nb = 1u << (c - 1);
+    const uint32_t nkeys = nmsm * W * nb;
+    const uint32_t seg = nb < 32 ? nb : 32, nsegpw = nb / seg;
+    const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
+    counts.ensure((size_t)(nkeys + 1) * 4); starts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
+    blocksum.ensure((size_t)(nblocks + 1) * 4);
+    entries.ensure((size_t)(total ? total : 1) * W * 4);
+    buckets.ensure((size_t)nkeys * sizeof(ge_ext));
+    partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
+    HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)(nkeys + 1) * 4, st));
+    if (total) hipLaunchKernelGGL(k_msm_digits<0>, dim3(cdiv(total, 256)), dim3(256), 0, st, S, total, c, W, nb, counts.as<uint32_t>(), (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_blocksums, dim3(nblocks), dim3(256), 0, st, counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, blocksum.as<uint32_t>(), nblocks);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(256), 0, st, counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
+    if (total) hipLaunchKernelGGL(k_msm_digits<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, S, total, c, W, nb, cursor.as<uint32_t>(), entries.as<uint32_t>());
+    hipLaunchKernelGGL(k_bucket_acc, dim3(cdiv(nkeys, 256)), dim3(256), 0, st, S, starts.as<uint32_t>(), entries.as<uint32_t>(), buckets.as<ge_ext>(), nkeys);
+    const uint32_t nred = nmsm * W * nsegpw;
+    hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), 0, st, buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
+    hipLaunchKernelGGL(k_msm_final, dim3(nmsm), dim3(256), 0, st, partial.as<ge_ext>(), d_result, W, nsegpw, c);
+    HIPCHK(hipGetLastError());
+}
+
+namespace {
+void seg_push(MsmSegs &S, const scm *sc, const ge_niels *pts, uint32_t len, uint32_t msm) {
+    if (!len) return;
+    if (S.nseg >= BPG_MAX_SEGS) throw std::logic_error("too many MSM segments");
+    uint32_t k = S.nseg++;
+    S.sc[k] = sc; S.pts[k] = pts; S.len[k] = len; S.msm[k] = msm;
+    S.start[k + 1] = S.start[k] + len;
+}
+MsmSegs seg_new() { MsmSegs S; std::memset(&S, 0, sizeof S); return S; }
+}  // namespace
+
+void Engine::msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]) {
+    if (first + count > gens_cap_) throw std::invalid_argument("msm_gens: range beyond capacity");
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    I.small_sc.ensure(2 * count * 32 + 64); I.sLR.ensure(2 * count * sizeof(scm) + 64);
+    I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(128);
+    if (count) {
+        HIPCHK(hipMemcpyAsync(I.small_sc.p, s, count * 32, hipMemcpyHostToDevice, I.st));
+        HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + count * 32, t, count * 32, hipMemcpyHostToDevice, I.st));
+        hipLaunchKernelGGL(k_sc_from_bytes, dim3(cdiv(2 * count, 256)), dim3(256), 0, I.st, I.small_sc.as<uint32_t>(), I.sLR.as<scm>(), (uint32_t)(2 * count));
+    }
+    MsmSegs S = seg_new();
+    seg_push(S, I.sLR.as<scm>(), I.gens.as<ge_niels>() + first, (uint32_t)count, 0);
+    seg_push(S, I.sLR.as<scm>() + count, I.gens.as<ge_niels>() + gens_cap_ + first, (uint32_t)count, 0);
+    I.msm(S, 1, I.msm_result.as<ge_ext>());
+    hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, I.st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, I.comp.p, 32, hipMemcpyDeviceToHost, I.st));
+    HIPCHK(hipStreamSynchronize(I.st));
+}
+
+// ------------------------------------------------------------------------------------------------ circuit upload
+DeviceCircuit *Engine::upload(const FlatCircuit &c) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    const uint64_t n = c.n, m = c.m, q = c.row_ptr.size() - 1, nnz = c.term_var.size(), ncoef = c.coef.size() / 32;
+    if (c.aL.size() != n * 32 || c.aR.size() != n * 32 || c.aO.size() != n * 32) throw std::invalid_argument("upload: witness vectors must hold n scalars");
+    if (c.row_ptr.front() != 0 || c.row_ptr.back() != nnz || c.term_coef.size() != nnz) throw std::invalid_argument("upload: malformed CSR");
+    if (n >= (1u << 27)) throw std::invalid_argument("upload: too many multipliers");
+    // CSR (by constraint) -> CSC (by variable) on the host; columns: [0,n) left, [n,2n) right, [2n,3n) output, [3n,3n+m) committed
+    const uint64_t ncols = 3 * n + m;
+    std::vector<uint64_t> col_ptr(ncols + 1, 0);
+    auto col_of = [&](uint32_t pv) -> int64_t {
+        uint32_t kind = pv >> 29, idx = pv & 0x1fffffffu;
+        if (kind <= 2) { if (idx >= n) throw std::invalid_argument("upload: multiplier index out of range"); return (int64_t)(kind * n + idx); }
+        if (kind == 3) { if (idx >= m) throw std::invalid_argument("upload: committed index out of range"); return (int64_t)(3 * n + idx); }
+        if (kind == 4) return -1;                       // Variable::One: ignored by the prover
+        throw std::invalid_argument("upload: bad variable kind");
+    };
+    for (uint64_t k = 0; k < nnz; k++) {
+        if (c.term_coef[k] >= ncoef) throw std::invalid_argument("upload: coefficient index out of range");
+        int64_t col = col_of(c.term_var[k]); if (col >= 0) col_ptr[col + 1]++;
+    }
+    for (uint64_t i = 0; i < ncols; i++) col_ptr[i + 1] += col_ptr[i];
+    const uint64_t kept = col_ptr[ncols];
+    std::vector<uint32_t> ent_row(kept ? kept : 1), ent_coef(kept ? kept : 1);
+    std::vector<uint64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
+    for (uint64_t r = 0; r < q; r++)
+        for (uint64_t k = c.row_ptr[r]; k < c.row_ptr[r + 1]; k++) {
+            int64_t col = col_of(c.term_var[k]); if (col < 0) continue;
+            uint64_t pos = fill[col]++; ent_row[pos] = (uint32_t)r; ent_coef[pos] = c.term_coef[k];
+        }
+    DeviceCircuit *d = new DeviceCircuit();
+    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept;
+    try {
+        d->aL.ensure((n ? n : 1) * sizeof(scm)); d->aR.ensure((n ? n : 1) * sizeof(scm)); d->aO.ensure((n ? n : 1) * sizeof(scm));
+        d->col_ptr.ensure((ncols + 1) * 8); d->ent_row.ensure(ent_row.size() * 4); d->ent_coef.ensure(ent_coef.size() * 4);
+        d->coef.ensure((ncoef ? ncoef : 1) * sizeof(scm));
+        const size_t maxn = std::max<uint64_t>(n, ncoef);
+        I.small_sc.ensure((maxn ? maxn : 1) * 32);
+        const std::vector<uint8_t> *src[4] = {&c.aL, &c.aR, &c.aO, &c.coef};
+        DevBuf *dst[4] = {&d->aL, &d->aR, &d->aO, &d->coef};
+        const uint64_t cnts[4] = {n, n, n, ncoef};
+        for (int k = 0; k < 4; k++) {
+            if (!cnts[k]) continue;
+            HIPCHK(hipMemcpyAsync(I.small_sc.p, src[k]->data(), cnts[k] * 32, hipMemcpyHostToDevice, I.st));
+            hipLaunchKernelGGL(k_sc_from_bytes, dim3(cdiv(cnts[k], 256)), dim3(256), 0, I.st, I.small_sc.as<uint32_t>(), dst[k]->as<scm>(), (uint32_t)cnts[k]);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(I.st));
+        }
+        HIPCHK(hipMemcpyAsync(d->col_ptr.p, col_ptr.data(), (ncols + 1) * 8, hipMemcpyHostToDevice, I.st));
+        HIPCHK(hipMemcpyAsync(d->ent_row.p, ent_row.data(), ent_row.size() * 4, hipMemcpyHostToDevice, I.st));
+        HIPCHK(hipMemcpyAsync(d->ent_coef.p, ent_coef.data(), ent_coef.size() * 4, hipMemcpyHostToDevice, I.st));
+        HIPCHK(hipStreamSynchronize(I.st));
+    } catch (...) { free_circuit(d); throw; }
+    return d;
+}
+
+void Engine::free_circuit(DeviceCircuit *c) {
+    if (!c) return;
+    (void)hipSetDevice(device_);
+    DevBuf *b[] = {&c->aL, &c->aR, &c->aO, &c->col_ptr, &c->ent_row, &c->ent_coef, &c->coef};
+    for (DevBuf *x : b) x->release();
+    delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ prove
+std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
+                                   const uint8_t rng_seed[32], uint32_t flags, ProveTimings *tm) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    hipStream_t st = I.st;
+    const uint64_t n = c->n, m = c->m, q = c->q;
+    if (v_blinding.size() != m) throw std::invalid_argument("prove: need one blinding factor per committed variable");
+    uint64_t N = 1; while (N < n) N <<= 1;
+    const uint32_t lgN = ceil_log2(N);
+    if (gens_cap_ < N) throw R1CSException(R1CSError::InvalidGeneratorsLength, "generator capacity below padded circuit size");
+    const bool compact = flags & 1u, no_1phase = flags & 2u;
+    const double t_begin = now_ms();
+    double t0 = t_begin;
+    auto lap = [&](double *slot) { if (tm) { HIPCHK(hipStreamSynchronize(st)); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
+
+    const ge_niels *Gtab = I.gens.as<ge_niels>(), *Htab = I.gens.as<ge_niels>() + gens_cap_;
+    const ge_niels *Bn = I.bases.as<ge_niels>(), *Bbn = Bn + 1;
+
+    // ---- transcript, RNG, first blindings
+    T.append_u64("m", m);
+    TranscriptRng rng = T.build_rng(v_blinding, rng_seed);
+    const Scalar ib = rng.random_scalar(), ob = rng.random_scalar(), sb = rng.random_scalar();
+
+    // small device scalars: extras[0..2] = ib, ob, sb ; [3..4] = cL*w, cR*w (per round)
+    I.extras.ensure(16 * sizeof(scm));
+    I.h_small.ensure(1 << 16);
+    {
+        scm *hs = I.h_small.as<scm>();
+        hs[0] = to_scm(ib); hs[1] = to_scm(ob); hs[2] = to_scm(sb);
+        HIPCHK(hipMemcpyAsync(I.extras.p, hs, 3 * sizeof(scm), hipMemcpyHostToDevice, st));
+    }
+    I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
+
+    // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
+    {
+        MsmSegs S = seg_new();
+        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
+        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
+        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
+        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
+        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+        I.msm(S, 2, I.msm_result.as<ge_ext>());
+    }
+    const double t_rng0 = now_ms();
+    I.h_raw.ensure((2 * n ? 2 * n : 1) * 64);
+    {
+        uint8_t *raw = I.h_raw.as<uint8_t>();
+        for (uint64_t i = 0; i < 2 * n; i++) rng.fill_bytes(raw + 64 * i, 64);      // s_L[0..n) then s_R[0..n)
+    }
+    if (tm) tm->rng_host += now_ms() - t_rng0;
+    I.raw_rng.ensure((2 * n ? 2 * n : 1) * 64); I.sLR.ensure((2 * n ? 2 * n : 1) * sizeof(scm));
+    scm *sL = I.sLR.as<scm>(), *sR = sL + n;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(I.raw_rng.p, I.h_raw.p, 2 * n * 64, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, I.raw_rng.as<uint32_t>(), sL, (uint32_t)(2 * n));
+    }
+    lap(tm ? &tm->msm_aiao : nullptr);
+    {
+        MsmSegs S = seg_new();
+        seg_push(S, sL, Gtab, (uint32_t)n, 0);
+        seg_push(S, sR, Htab, (uint32_t)n, 0);
+        seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 0);
+        I.msm(S, 1, I.msm_result.as<ge_ext>() + 2);
+    }
+    hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
+    HIPCHK(hipGetLastError());
+    uint8_t pts[96];
+    HIPCHK(hipMemcpyAsync(pts, I.comp.p, 96, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap(tm ? &tm->msm_s : nullptr);
+
+    std::vector<uint8_t> proof;
+    proof.reserve(14 * 32 + (2 * lgN + 2) * 32 + 1);
+    if (compact) proof.push_back(0);
+    proof.insert(proof.end(), pts, pts + 96);
+    T.append_point("A_I1", pts); T.append_point("A_O1", pts + 32); T.append_point("S1", pts + 64);
+    if (!no_1phase) T.r1cs_1phase_domain_sep();
+    const uint8_t ident[32] = {0};
+    T.append_point("A_I2", ident); T.append_point("A_O2", ident); T.append_point("S2", ident);
+    if (!compact) proof.insert(proof.end(), 96, 0);
+
+    const Scalar y = T.challenge_scalar("y"), z = T.challenge_scalar("z");
+    const Scalar yinv = y.invert();
+
+    // ---- powers, flattened weights, t-polynomial
+    I.ypow.ensure(N * sizeof(scm)); I.yinvpow.ensure(N * sizeof(scm)); I.zpow.ensure((q + 2) * sizeof(scm));
+    I.wAll.ensure((c->ncols ? c->ncols : 1) * sizeof(scm));
+    auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
+        uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
+        hipLaunchKernelGGL(k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), 0, st, to_scm(base), out, (uint32_t)count, lgT);
+    };
+    exp_table(y, I.ypow.as<scm>(), N);
+    exp_table(yinv, I.yinvpow.as<scm>(), N);
+    exp_table(z, I.zpow.as<scm>(), q + 1);
+    if (c->ncols)
+        hipLaunchKernelGGL(k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), 0, st, c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
+                           c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)c->ncols, (uint32_t)(3 * n));
+    scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;
+    const uint32_t pblocks = n ? std::min<uint32_t>(cdiv(n, 256), 1024) : 1;
+    I.red_partial.ensure((size_t)pblocks * 6 * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
+    hipLaunchKernelGGL(k_poly_t, dim3(pblocks), dim3(256), 0, st, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
+                       I.ypow.as<scm>(), I.yinvpow.as<scm>(), I.red_partial.as<scm>(), (uint32_t)n);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(6), dim3(256), 0, st, I.red_partial.as<scm>(), pblocks, 6u, I.red_out.as<scm>());
+    HIPCHK(hipGetLastError());
+    scm h_t[6]; std::vector<scm> h_wV(m ? m : 1);
+    HIPCHK(hipMemcpyAsync(h_t, I.red_out.p, 6 * sizeof(scm), hipMemcpyDeviceToHost, st));
+    if (m) HIPCHK(hipMemcpyAsync(h_wV.data(), wV, m * sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    Scalar t[7], tb[7];
+    for (int k = 0; k < 6; k++) t[k + 1] = from_scm(h_t[k]);
+    tb[1] = rng.random_scalar(); tb[3] = rng.random_scalar(); tb[4] = rng.random_scalar(); tb[5] = rng.random_scalar(); tb[6] = rng.random_scalar();
+    {   // T_1, T_3, T_4, T_5, T_6 = t_k * B + tau_k * B_blinding
+        uint8_t vv[5 * 32], rr[5 * 32], out[5 * 32];
+        const int idx[5] = {1, 3, 4, 5, 6};
+        for (int k = 0; k < 5; k++) { t[idx[k]].to_bytes(vv + 32 * k); tb[idx[k]].to_bytes(rr + 32 * k); }
+        pedersen_commit(5, vv, rr, out);
+        static const char *labels[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
+        for (int k = 0; k < 5; k++) T.append_point(labels[k], out + 32 * k);
+        proof.insert(proof.end(), out, out + 160);
+    }
+    const Scalar u_ch = T.challenge_scalar("u"), x = T.challenge_scalar("x");
+    for (uint64_t j = 0; j < m; j++) tb[2] += from_scm(h_wV[j]) * v_blinding[j];
+    Scalar tx, txb;
+    for (int k = 6; k >= 1; k--) { tx = (tx + t[k]) * x; txb = (txb + tb[k]) * x; }
+    const Scalar eb = x * (ib + x * (ob + x * sb));
+    T.append_scalar("t_x", tx); T.append_scalar("t_x_blinding", txb); T.append_scalar("e_blinding", eb);
+    { uint8_t b[96]; tx.to_bytes(b); txb.to_bytes(b + 32); eb.to_bytes(b + 64); proof.insert(proof.end(), b, b + 96); }
+    const Scalar w = T.challenge_scalar("w");
+
+    I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm));
+    hipLaunchKernelGGL(k_poly_eval, dim3(cdiv(N, 256)), dim3(256), 0, st, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
+                       I.ypow.as<scm>(), I.yinvpow.as<scm>(), to_scm(x), I.lv.as<scm>(), I.rv.as<scm>(), (uint32_t)n, (uint32_t)N);
+    HIPCHK(hipGetLastError());
+    lap(tm ? &tm->poly : nullptr);
+
+    // ---- inner-product argument
+    T.innerproduct_domain_sep(N);
+    std::vector<Scalar> yinv_pow2(lgN + 1);
+    yinv_pow2[0] = yinv; for (uint32_t k = 1; k <= lgN; k++) yinv_pow2[k] = yinv_pow2[k - 1] * yinv_pow2[k - 1];
+    scm *a = I.lv.as<scm>(), *b = I.rv.as<scm>();
+    if (lgN) {
+        const uint64_t half = N / 2;
+        I.ipa_s.ensure(4 * half * sizeof(scm));
+        I.ipa_tabA.ensure(2 * half * sizeof(ge_niels)); I.ipa_tabB.ensure((half > 1 ? half : 2) * sizeof(ge_niels));
+        I.scratch_ext.ensure(2 * half * sizeof(ge_ext));
+        I.naf.ensure(sizeof(FoldNaf));
+    }
+    Scalar Gamma = Scalar::one(), Eta = Scalar::one();
+    const ge_niels *Gst = Gtab, *Hst = Htab;
+    const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
+    uint64_t mcur = N;
+    for (uint32_t round = 0; round < lgN; round++) {
+        const uint64_t h = mcur / 2;
+        const bool first = round == 0;
+        scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + h, *sRG = sLH + h, *sRH = sRG + h;
+        const uint32_t blocks = std::min<uint32_t>(cdiv(h, 256), 1024);
+        I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
+        hipLaunchKernelGGL(k_ipa_prep, dim3(blocks), dim3(256), 0, st, a, b, I.yinvpow.as<scm>(), to_scm(Gamma), to_scm(Eta), uch_m,
+                           (uint32_t)first, (uint32_t)n, (uint32_t)h, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
+        hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(256), 0, st, I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
+        hipLaunchKernelGGL(k_scale2, dim3(1), dim3(64), 0, st, I.extras.as<scm>() + 3, w_m);
+        {
+            MsmSegs S = seg_new();
+            seg_push(S, sLG, Gst + h, (uint32_t)h, 0);
+            seg_push(S, sLH, Hst, (uint32_t)h, 0);
+            seg_push(S, I.extras.as<scm>() + 3, Bn, 1, 0);
+            seg_push(S, sRG, Gst, (uint32_t)h, 1);
+            seg_push(S, sRH, Hst + h, (uint32_t)h, 1);
+            seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
+            I.msm(S, 2, I.msm_result.as<ge_ext>());
+        }
+        hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
+        HIPCHK(hipGetLastError());
+        uint8_t lr[64];
+        HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        lap(tm ? &tm->ipa_msm : nullptr);
+        T.append_point("L", lr); T.append_point("R", lr + 32);
+        proof.insert(proof.end(), lr, lr + 64);
+        const Scalar u = T.challenge_scalar("u"), uinv = u.invert();
+        hipLaunchKernelGGL(k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), 0, st, a, b, to_scm(u), to_scm(uinv), (uint32_t)h);
+        if (h > 1 || true) {
+            // generator fold: Gst'[i] = Gst[i] + sG * Gst[h+i],  Hst'[i] = Hst[i] + sH * Hst[h+i]
+            const Scalar sGA = u * u, sHA = uinv * uinv * yinv_pow2[ceil_log2(h)];
+            FoldNaf *hn = reinterpret_cast<FoldNaf *>(I.h_small.as<uint8_t>() + 4096);
+            hn->top[0] = naf256(sGA, hn->d[0]);
+            hn->top[2] = naf256(sHA, hn->d[2]);
+            if (first) { hn->top[1] = naf256(sGA * u_ch, hn->d[1]); hn->top[3] = naf256(sHA * u_ch, hn->d[3]); }
+            else { std::memcpy(hn->d[1], hn->d[0], 256); hn->top[1] = hn->top[0]; std::memcpy(hn->d[3], hn->d[2], 256); hn->top[3] = hn->top[2]; }
+            HIPCHK(hipMemcpyAsync(I.naf.p, hn, sizeof(FoldNaf), hipMemcpyHostToDevice, st));
+            const uint32_t split = first ? (uint32_t)(n - h) : (uint32_t)h;
+            ge_niels *dst = (round & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            hipLaunchKernelGGL(k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), 0, st, Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<FoldNaf>(), (uint32_t)h, split);
+            hipLaunchKernelGGL(k_normalize_niels, dim3(cdiv(cdiv(2 * h, NORM_K), 256)), dim3(256), 0, st, I.scratch_ext.as<ge_ext>(), dst, (uint32_t)(2 * h));
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));      // hn (pinned) is rewritten next round
+            Gst = dst; Hst = dst + h;
+        }
+        Gamma = uinv * Gamma; Eta = u * Eta;
+        mcur = h;
+        lap(tm ? &tm->ipa_fold : nullptr);
+    }
+    scm ab[2];
+    HIPCHK(hipMemcpyAsync(&ab[0], a, sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&ab[1], b, sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    { uint8_t o[64]; from_scm(ab[0]).to_bytes(o); from_scm(ab[1]).to_bytes(o + 32); proof.insert(proof.end(), o, o + 64); }
+    if (tm) { tm->ipa = tm->ipa_msm + tm->ipa_fold; tm->total += now_ms() - t_begin; }
+    return proof;
+}
+
+}  // namespace bpg

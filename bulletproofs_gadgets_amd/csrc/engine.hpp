@@ -1,0 +1,56 @@
+// HIP engine behind the C ABI (include/bpg.h): owns the device, the generator tables resident in HBM, the MSM
+// workspace and the prove pipeline.  There is NO CPU execution path: construction throws when no GPU is present.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "host/scalar.hpp"
+#include "host/merlin.hpp"
+#include "host/r1cs.hpp"
+
+namespace bpg {
+
+struct DeviceError : std::runtime_error { explicit DeviceError(const std::string &m) : std::runtime_error(m) {} };
+
+struct ProveTimings {       // milliseconds, host wall clock around each phase (stream synchronised at phase ends)
+    double rng_host = 0, msm_aiao = 0, msm_s = 0, poly = 0, ipa = 0, total = 0;
+    double ipa_msm = 0, ipa_fold = 0, ipa_sync = 0;
+};
+
+struct DeviceCircuit;       // HBM-resident flattened R1CS instance
+
+class Engine {
+public:
+    explicit Engine(int device);
+    ~Engine();
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+
+    int device() const { return device_; }
+    // BulletproofGens::new(capacity, 1): derive (or extend) the G/H tables in HBM; capacity must be a power of two
+    void gens_ensure(uint64_t capacity);
+    uint64_t gens_capacity() const { return gens_cap_; }
+    void gens_export(uint64_t first, uint64_t count, uint8_t *G_out, uint8_t *H_out);
+    void pedersen_bases(uint8_t B[32], uint8_t B_blinding[32]);
+    // k Pedersen commitments v_i*B + r_i*B_blinding (compressed). v may be unreduced (< 2^255); r any 256-bit value.
+    void pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, uint8_t *out);
+    // multiscalar multiplication over generator-table slices, for tests: sum s_i * G[first+i] + t_i * H[first+i]
+    void msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
+
+    DeviceCircuit *upload(const FlatCircuit &c);
+    void free_circuit(DeviceCircuit *c);
+    // Prover::prove on a resident circuit. transcript: state after Prover::new + every "V" append (updated in place).
+    std::vector<uint8_t> prove(DeviceCircuit *c, Transcript &transcript, const std::vector<Scalar> &v_blinding,
+                               const uint8_t rng_seed[32], uint32_t flags, ProveTimings *timings = nullptr);
+    void synchronize();
+    void *stream_handle() const { return stream_; }
+    // names of the kernels launched by the last prove(), with counts (diagnostics for bench.py)
+    struct Impl;
+private:
+    int device_;
+    void *stream_ = nullptr;
+    uint64_t gens_cap_ = 0;
+    Impl *impl_ = nullptr;
+};
+
+}  // namespace bpg

@@ -15,7 +15,7 @@
 
 namespace bpg {
 
-struct fe { uint32_t v[8]; };
+struct alignas(16) fe { uint32_t v[8]; };
 
 BPG_HD fe fe_zero() { fe r; BPG_UNROLL for (int i = 0; i < 8; i++) r.v[i] = 0; return r; }
 BPG_HD fe fe_one() { fe r = fe_zero(); r.v[0] = 1; return r; }

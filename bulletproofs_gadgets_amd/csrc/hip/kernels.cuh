@@ -1,0 +1,428 @@
+// HIP kernels of the Bulletproofs R1CS prove path for gfx950 (MI355X).  Integer VALU work (v_mad_u64_u32 chains);
+// no MFMA - this is 255-bit modular arithmetic, not a dense contraction.  Hot-path rows of SURVEY.md section 8(a):
+//   a7  BulletproofGens::new            k_gens_derive + k_normalize_niels
+//   a1-a3,a6  Pedersen commits          k_pedersen
+//   a9  A_I, A_O, S multiscalar muls    k_msm_* (bucket method: digit histogram -> scan -> scatter -> bucket sweep)
+//   a10 vector-polynomial phase         k_exp_table, k_flatten, k_poly_t, k_poly_eval, k_reduce_partials
+//   a11 inner-product argument          k_ipa_prep, k_ipa_fold_scalars, k_fold_points (+ the MSM kernels)
+// Data layout in HBM: scalars = 8 x u32 Montgomery form, 32 B each, AoS (lane i <-> element i: 2 x 16 B coalesced
+// loads); generator tables = affine Niels (y+x, y-x, 2dxy), 96 B per point, G at [0,N) and H at [N,2N).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ge.cuh"
+#include "sc.cuh"
+
+namespace bpg {
+
+#define BPG_MAX_SEGS 8
+struct MsmSegs {
+    const scm *sc[BPG_MAX_SEGS];
+    const ge_niels *pts[BPG_MAX_SEGS];
+    uint32_t len[BPG_MAX_SEGS];
+    uint32_t start[BPG_MAX_SEGS + 1];   // prefix of len
+    uint32_t msm[BPG_MAX_SEGS];
+    uint32_t nseg;
+};
+
+// ------------------------------------------------------------------------------------------------ generators
+// one thread per generator: 64 uniform bytes -> Ristretto point (two Elligator maps + add), extended coordinates
+__global__ void __launch_bounds__(256) k_gens_derive(const uint32_t *__restrict__ uniform, ge_ext *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[16];
+    const uint4 *src = reinterpret_cast<const uint4 *>(uniform + 16 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    out[i] = ge_from_uniform_words(w);
+}
+
+// extended -> affine Niels with one field inversion per NORM_K points (Montgomery's trick inside a thread).
+// Thread t handles points t, t+T, t+2T, ... so that loads and stores stay coalesced.
+#define NORM_K 8
+__global__ void __launch_bounds__(256) k_normalize_niels(const ge_ext *__restrict__ in, ge_niels *__restrict__ out, uint32_t count) {
+    uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    fe pre[NORM_K];
+    fe acc = fe_one();
+#pragma unroll
+    for (int k = 0; k < NORM_K; k++) {
+        uint32_t idx = t + k * T;
+        pre[k] = acc;
+        if (idx < count) acc = fe_mul(acc, in[idx].Z);
+    }
+    fe inv = fe_invert(acc);
+#pragma unroll
+    for (int k = NORM_K - 1; k >= 0; k--) {
+        uint32_t idx = t + k * T;
+        if (idx < count) {
+            ge_ext p = in[idx];
+            fe zinv = fe_mul(inv, pre[k]);
+            inv = fe_mul(inv, p.Z);
+            out[idx] = ge_to_niels(p, zinv);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_compress(const ge_ext *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_compress(out + 32 * (size_t)i, in[i]);
+}
+__global__ void __launch_bounds__(64) k_compress_niels(const ge_niels *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_compress(out + 32 * (size_t)i, ge_madd(ge_identity(), in[i]));
+}
+
+// bases[0] = B, bases[1] = B_blinding = from_uniform(SHA3-512(compress(B))) (hash computed on the host), bases[2] = B + B_blinding
+__global__ void k_init_bases(const uint32_t *__restrict__ hash64, ge_niels *__restrict__ bases) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ge_ext B;
+    B.X = BPG_FE(0x918de5d2u, 0x2f4183e0u, 0xa8a67c6cu, 0x40971ffau, 0x6803537au, 0xdd5bff85u, 0x8cfe80c3u, 0x1063e2ccu);
+    B.Y = BPG_FE(0xf533ad9bu, 0xcc7edf80u, 0x4253df49u, 0x5d14c8bau, 0x0fc4ed5bu, 0x061b3d57u, 0xe44c3c7fu, 0x159a6849u);
+    B.Z = fe_one(); B.T = fe_mul(B.X, B.Y);
+    uint32_t w[16];
+    for (int i = 0; i < 16; i++) w[i] = hash64[i];
+    ge_ext Bb = ge_from_uniform_words(w);
+    ge_ext S = ge_add(B, Bb);
+    bases[0] = ge_to_niels(B, fe_one());
+    bases[1] = ge_to_niels(Bb, fe_invert(Bb.Z));
+    bases[2] = ge_to_niels(S, fe_invert(S.Z));
+}
+
+// Pedersen commitments v*B + r*B_blinding, one per thread (Shamir's trick over the 3-entry base table), compressed.
+// v, r are plain 256-bit little-endian integers below 2^255 (v may be an unreduced Scalar::from_bits value).
+__global__ void __launch_bounds__(64) k_pedersen(const uint32_t *__restrict__ v, const uint32_t *__restrict__ r,
+                                                 const ge_niels *__restrict__ bases, uint8_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t vw[8], rw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { vw[k] = v[8 * (size_t)i + k]; rw[k] = r[8 * (size_t)i + k]; }
+    ge_ext acc = ge_identity();
+    for (int b = 254; b >= 0; b--) {
+        acc = ge_dbl(acc);
+        uint32_t sel = ((vw[b >> 5] >> (b & 31)) & 1u) | (((rw[b >> 5] >> (b & 31)) & 1u) << 1);
+        if (sel) acc = ge_madd(acc, bases[sel - 1]);
+    }
+    ge_compress(out + 32 * (size_t)i, acc);
+}
+
+// ------------------------------------------------------------------------------------------------ scalar vectors
+__global__ void __launch_bounds__(256) k_sc_from_bytes(const uint32_t *__restrict__ in, scm *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[8];
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + 8 * (size_t)i);
+    uint4 a = src[0], b = src[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    out[i] = sc_from_words(w);
+}
+// 64-byte TranscriptRng draws -> scalars (Scalar::random = from_bytes_mod_order_wide)
+__global__ void __launch_bounds__(256) k_sc_from_wide(const uint32_t *__restrict__ in, scm *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[16];
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + 16 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    out[i] = sc_from_wide_words(w);
+}
+__global__ void __launch_bounds__(256) k_sc_to_bytes(const scm *__restrict__ in, uint32_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[8]; sc_to_words(w, in[i]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[8 * (size_t)i + k] = w[k];
+}
+
+// out[i] = base^i for i < count (Montgomery form). Thread t walks i = t, t+T, ... multiplying by base^T; T = 2^lgT.
+__global__ void __launch_bounds__(256) k_exp_table(scm base, scm *__restrict__ out, uint32_t count, uint32_t lgT) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t T = 1u << lgT;
+    if (t >= T) return;
+    scm cur = SC_R1(), sq = base;
+    for (uint32_t b = 0; b < lgT; b++) {           // cur = base^t ; sq ends as base^T
+        if ((t >> b) & 1u) cur = sc_mont_mul(cur, sq);
+        sq = sc_mont_mul(sq, sq);
+    }
+    for (uint32_t i = t; i < count; i += T) { out[i] = cur; cur = sc_mont_mul(cur, sq); }
+}
+
+// block-wide sum of one scalar per thread (256 threads) through LDS; result valid in thread 0
+__device__ __forceinline__ scm block_sum_256(scm v, scm *lds) {
+    lds[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) lds[threadIdx.x] = sc_add(lds[threadIdx.x], lds[threadIdx.x + s]);
+        __syncthreads();
+    }
+    scm r = lds[0];
+    __syncthreads();
+    return r;
+}
+
+// out[k] = sum over parts of partial[p * stride + k], k < nsum   (one block per output scalar)
+__global__ void __launch_bounds__(256) k_reduce_partials(const scm *__restrict__ partial, uint32_t parts, uint32_t stride, scm *__restrict__ out) {
+    __shared__ scm lds[256];
+    uint32_t k = blockIdx.x;
+    scm acc = sc_zero();
+    for (uint32_t p = threadIdx.x; p < parts; p += 256) acc = sc_add(acc, partial[(size_t)p * stride + k]);
+    scm r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[k] = r;
+}
+
+// flattened_constraints(z): column-major gather. Column c (0..3n+m): w[c] = sum_e coef[ent_coef[e]] * z^(ent_row[e]+1);
+// columns [3n, 3n+m) are the committed variables and come out negated (wV).
+__global__ void __launch_bounds__(256) k_flatten(const uint64_t *__restrict__ col_ptr, const uint32_t *__restrict__ ent_row,
+                                                 const uint32_t *__restrict__ ent_coef, const scm *__restrict__ coef,
+                                                 const scm *__restrict__ zpow /* z^j, j >= 0 */, scm *__restrict__ w,
+                                                 uint32_t ncols, uint32_t first_neg_col) {
+    uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    scm acc = sc_zero();
+    for (uint64_t e = col_ptr[c]; e < col_ptr[c + 1]; e++) acc = sc_add(acc, sc_mont_mul(coef[ent_coef[e]], zpow[ent_row[e] + 1]));
+    w[c] = (c >= first_neg_col) ? sc_neg(acc) : acc;
+}
+
+// t1..t6 partial sums of <l(X), r(X)>:  l1 = aL + y^-i wR, l2 = aO, l3 = sL ; r0 = wO - y^i, r1 = y^i aR + wL, r3 = y^i sR
+__global__ void __launch_bounds__(256) k_poly_t(const scm *__restrict__ aL, const scm *__restrict__ aR, const scm *__restrict__ aO,
+                                                const scm *__restrict__ sL, const scm *__restrict__ sR,
+                                                const scm *__restrict__ wL, const scm *__restrict__ wR, const scm *__restrict__ wO,
+                                                const scm *__restrict__ ypow, const scm *__restrict__ yinvpow,
+                                                scm *__restrict__ partial /* gridDim.x * 6 */, uint32_t n) {
+    __shared__ scm lds[256];
+    scm t1 = sc_zero(), t2 = t1, t3 = t1, t4 = t1, t5 = t1, t6 = t1;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        scm y = ypow[i];
+        scm l1 = sc_add(aL[i], sc_mont_mul(yinvpow[i], wR[i]));
+        scm l2 = aO[i], l3 = sL[i];
+        scm r0 = sc_sub(wO[i], y);
+        scm r1 = sc_add(sc_mont_mul(y, aR[i]), wL[i]);
+        scm r3 = sc_mont_mul(y, sR[i]);
+        t1 = sc_add(t1, sc_mont_mul(l1, r0));
+        t2 = sc_add(t2, sc_add(sc_mont_mul(l1, r1), sc_mont_mul(l2, r0)));
+        t3 = sc_add(t3, sc_add(sc_mont_mul(l2, r1), sc_mont_mul(l3, r0)));
+        t4 = sc_add(t4, sc_add(sc_mont_mul(l1, r3), sc_mont_mul(l3, r1)));
+        t5 = sc_add(t5, sc_mont_mul(l2, r3));
+        t6 = sc_add(t6, sc_mont_mul(l3, r3));
+    }
+    scm r;
+    r = block_sum_256(t1, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 0] = r;
+    r = block_sum_256(t2, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 1] = r;
+    r = block_sum_256(t3, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 2] = r;
+    r = block_sum_256(t4, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 3] = r;
+    r = block_sum_256(t5, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 4] = r;
+    r = block_sum_256(t6, lds); if (threadIdx.x == 0) partial[blockIdx.x * 6 + 5] = r;
+}
+
+// l(x) = x (l1 + x (l2 + x l3)),  r(x) = r0 + x (r1 + x^2 r3); padding i in [n, N): l = 0, r = -y^i
+__global__ void __launch_bounds__(256) k_poly_eval(const scm *__restrict__ aL, const scm *__restrict__ aR, const scm *__restrict__ aO,
+                                                   const scm *__restrict__ sL, const scm *__restrict__ sR,
+                                                   const scm *__restrict__ wL, const scm *__restrict__ wR, const scm *__restrict__ wO,
+                                                   const scm *__restrict__ ypow, const scm *__restrict__ yinvpow, scm x,
+                                                   scm *__restrict__ lv, scm *__restrict__ rv, uint32_t n, uint32_t N) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    scm y = ypow[i];
+    if (i >= n) { lv[i] = sc_zero(); rv[i] = sc_neg(y); return; }
+    scm l1 = sc_add(aL[i], sc_mont_mul(yinvpow[i], wR[i]));
+    scm r0 = sc_sub(wO[i], y);
+    scm r1 = sc_add(sc_mont_mul(y, aR[i]), wL[i]);
+    scm r3 = sc_mont_mul(y, sR[i]);
+    scm l = sc_mont_mul(x, sc_add(l1, sc_mont_mul(x, sc_add(aO[i], sc_mont_mul(x, sL[i])))));
+    scm r = sc_add(r0, sc_mont_mul(x, sc_add(r1, sc_mont_mul(x, sc_mont_mul(x, r3)))));
+    lv[i] = l; rv[i] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ inner-product rounds
+// Generators are kept UNSCALED: actual G_j = Gamma * gf(j) * Gst[j], actual H_j = Eta * y^-j * gf(j) * Hst[j], where
+// gf(j) = u_ch for j >= n in the first round (G_factors / H_factors of the R1CS padding) and 1 otherwise.
+// MSM scalars for L: a_lo[i]*Gamma*gf(h+i) on Gst[h+i], b_hi[i]*Eta*y^-i on Hst[i];
+//             for R: a_hi[i]*Gamma on Gst[i],           b_lo[i]*Eta*y^-(h+i)*gf(h+i) on Hst[h+i].
+// Also accumulates c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo> per block.
+__global__ void __launch_bounds__(256) k_ipa_prep(const scm *__restrict__ a, const scm *__restrict__ b, const scm *__restrict__ yinvpow,
+                                                  scm Gamma, scm Eta, scm u_ch, uint32_t first_round, uint32_t n, uint32_t h,
+                                                  scm *__restrict__ sLG, scm *__restrict__ sLH, scm *__restrict__ sRG, scm *__restrict__ sRH,
+                                                  scm *__restrict__ partial /* gridDim.x * 2 */) {
+    __shared__ scm lds[256];
+    scm cL = sc_zero(), cR = sc_zero();
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
+        scm alo = a[i], ahi = a[h + i], blo = b[i], bhi = b[h + i];
+        bool pad = first_round && (h + i >= n);
+        scm g = sc_mont_mul(alo, Gamma); if (pad) g = sc_mont_mul(g, u_ch);
+        sLG[i] = g;
+        sLH[i] = sc_mont_mul(sc_mont_mul(bhi, Eta), yinvpow[i]);
+        sRG[i] = sc_mont_mul(ahi, Gamma);
+        scm e = sc_mont_mul(sc_mont_mul(blo, Eta), yinvpow[h + i]); if (pad) e = sc_mont_mul(e, u_ch);
+        sRH[i] = e;
+        cL = sc_add(cL, sc_mont_mul(alo, bhi));
+        cR = sc_add(cR, sc_mont_mul(ahi, blo));
+    }
+    scm r;
+    r = block_sum_256(cL, lds); if (threadIdx.x == 0) partial[blockIdx.x * 2 + 0] = r;
+    r = block_sum_256(cR, lds); if (threadIdx.x == 0) partial[blockIdx.x * 2 + 1] = r;
+}
+// c[k] *= w   (k < 2): the Q = w*B term of L and R becomes a scalar on the fixed base B
+__global__ void k_scale2(scm *__restrict__ c, scm w) { if (threadIdx.x < 2 && blockIdx.x == 0) c[threadIdx.x] = sc_mont_mul(c[threadIdx.x], w); }
+
+__global__ void __launch_bounds__(256) k_ipa_fold_scalars(scm *__restrict__ a, scm *__restrict__ b, scm u, scm uinv, uint32_t h) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= h) return;
+    a[i] = sc_add(sc_mont_mul(a[i], u), sc_mont_mul(uinv, a[h + i]));
+    b[i] = sc_add(sc_mont_mul(b[i], uinv), sc_mont_mul(u, b[h + i]));
+}
+
+// Generator fold with a wave-uniform scalar: out[i] = P_i + s * Q_i, P_i = tab[i], Q_i = tab[h + i].
+// naf[k] in {-1,0,1} is the non-adjacent form of s (shared by every lane, so the add/skip branch never diverges).
+// Threads [0,h) fold G with nafG{A,B}, threads [h,2h) fold H with nafH{A,B}; class B applies to i >= split (first round only).
+struct FoldNaf { int8_t d[4][256]; int32_t top[4]; };
+__global__ void __launch_bounds__(256) k_fold_points(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H,
+                                                     ge_ext *__restrict__ out /* 2h */, const FoldNaf *__restrict__ naf,
+                                                     uint32_t h, uint32_t split) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * h) return;
+    const bool isH = t >= h;
+    const uint32_t i = isH ? t - h : t;
+    const ge_niels *tab = isH ? H : G;
+    const int cls = (isH ? 2 : 0) + (i >= split ? 1 : 0);
+    const ge_niels Q = tab[h + i];
+    const int8_t *d = naf->d[cls];
+    ge_ext acc = ge_identity();
+    for (int k = naf->top[cls]; k >= 0; k--) {
+        acc = ge_dbl(acc);
+        int8_t dk = d[k];
+        if (dk != 0) acc = ge_madd_signed(acc, Q, dk < 0);
+    }
+    out[t] = ge_madd(acc, tab[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ multiscalar multiplication
+// Signed c-bit digits of a canonical scalar (value < 2^253). digit w in (-2^(c-1), 2^(c-1)].
+__device__ __forceinline__ int32_t msm_digit(const uint32_t w[8], uint32_t c, uint32_t win, uint32_t &carry) {
+    uint32_t off = win * c, wi = off >> 5, sh = off & 31;
+    uint64_t two = (uint64_t)(wi < 8 ? w[wi] : 0u) | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+    uint32_t raw = (uint32_t)((two >> sh) & ((1u << c) - 1u)) + carry;
+    if (raw > (1u << (c - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << c); }
+    carry = 0; return (int32_t)raw;
+}
+__device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < BPG_MAX_SEGS; k++) if (k < S.nseg && g >= S.start[k]) s = k;
+    return s;
+}
+
+// pass 0: histogram (counts[key]++), pass 1: scatter entries to cursor[key]++.
+// key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment
+template <int PASS>
+__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, uint32_t total, uint32_t c, uint32_t W, uint32_t nb,
+                                                    uint32_t *__restrict__ counts_or_cursor, uint32_t *__restrict__ entries) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    uint32_t w[8]; sc_to_words(w, S.sc[s][i]);
+    uint32_t carry = 0, base = S.msm[s] * W;
+    for (uint32_t win = 0; win < W; win++) {
+        int32_t d = msm_digit(w, c, win, carry);
+        if (d == 0) continue;
+        uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+        uint32_t key = (base + win) * nb + (mag - 1);
+        if (PASS == 0) atomicAdd(&counts_or_cursor[key], 1u);
+        else { uint32_t pos = atomicAdd(&counts_or_cursor[key], 1u); entries[pos] = (neg << 31) | (s << 27) | i; }
+    }
+}
+
+// exclusive scan of counts[0..nkeys) in three launches (chunk = 2048 keys per block)
+#define SCAN_CHUNK 2048
+__global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restrict__ counts, uint32_t nkeys, uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t lds[256];
+    uint32_t base = blockIdx.x * SCAN_CHUNK, s = 0;
+    for (uint32_t k = threadIdx.x; k < SCAN_CHUNK; k += 256) if (base + k < nkeys) s += counts[base + k];
+    lds[threadIdx.x] = s; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = lds[0];
+}
+__global__ void k_scan_top(uint32_t *__restrict__ blocksum, uint32_t nblocks) {   // single thread: nblocks <= a few thousand
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nblocks; b++) { uint32_t v = blocksum[b]; blocksum[b] = run; run += v; }
+    blocksum[nblocks] = run;
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ counts, uint32_t nkeys, const uint32_t *__restrict__ blocksum,
+                                                    uint32_t *__restrict__ starts, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t lds[256];
+    uint32_t base = blockIdx.x * SCAN_CHUNK;
+    uint32_t v[8], s = 0;                       // thread owns 8 consecutive keys
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint32_t idx = base + threadIdx.x * 8 + k; v[k] = idx < nkeys ? counts[idx] : 0; s += v[k]; }
+    lds[threadIdx.x] = s; __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {     // inclusive Hillis-Steele scan
+        uint32_t x = threadIdx.x >= d ? lds[threadIdx.x - d] : 0; __syncthreads();
+        lds[threadIdx.x] += x; __syncthreads();
+    }
+    uint32_t run = blocksum[blockIdx.x] + lds[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t idx = base + threadIdx.x * 8 + k;
+        if (idx < nkeys) { starts[idx] = run; cursor[idx] = run; }
+        run += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) starts[nkeys] = blocksum[gridDim.x];
+}
+
+// bucket sweep: one thread per bucket walks its entry list (gathering 96-byte Niels points) and stores the bucket sum
+__global__ void __launch_bounds__(256) k_bucket_acc(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
+                                                    ge_ext *__restrict__ buckets, uint32_t nkeys) {
+    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    ge_ext acc = ge_identity();
+    uint32_t e0 = starts[key], e1 = starts[key + 1];
+    for (uint32_t e = e0; e < e1; e++) {
+        uint32_t ent = entries[e];
+        const ge_niels q = S.pts[(ent >> 27) & 7u][ent & 0x07ffffffu];
+        acc = ge_madd_signed(acc, q, ent >> 31);
+    }
+    buckets[key] = acc;
+}
+
+// per (msm, window, segment of SEG buckets): sum_b (b+1) * bucket[b] over the segment -> partial
+__global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__ buckets, ge_ext *__restrict__ partial,
+                                                     uint32_t nb, uint32_t seg, uint32_t nseg_per_win, uint32_t total) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint32_t win = t / nseg_per_win, sg = t % nseg_per_win;
+    uint32_t lo = sg * seg;
+    const ge_ext *B = buckets + (size_t)win * nb;
+    ge_ext run = ge_identity(), acc = ge_identity();
+    for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
+    // acc = sum (b - lo + 1) B_b ; add lo * run
+    ge_ext m = ge_identity();
+    for (int32_t k = 31; k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }
+    partial[t] = ge_add(acc, m);
+}
+
+// one block per msm: window sums from the partials, Horner over windows, result in extended coordinates
+__global__ void __launch_bounds__(256) k_msm_final(const ge_ext *__restrict__ partial, ge_ext *__restrict__ result,
+                                                  uint32_t W, uint32_t nseg_per_win, uint32_t c) {
+    __shared__ ge_ext lds[256];
+    const ge_ext *P = partial + (size_t)blockIdx.x * W * nseg_per_win;
+    ge_ext total = ge_identity();
+    for (int32_t win = (int32_t)W - 1; win >= 0; win--) {
+        ge_ext acc = ge_identity();
+        for (uint32_t s = threadIdx.x; s < nseg_per_win; s += 256) acc = ge_add(acc, P[(size_t)win * nseg_per_win + s]);
+        lds[threadIdx.x] = acc; __syncthreads();
+        for (uint32_t d = 128; d > 0; d >>= 1) {
+            if (threadIdx.x < d && threadIdx.x + d < nseg_per_win) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            if (win != (int32_t)W - 1) for (uint32_t k = 0; k < c; k++) total = ge_dbl(total);
+            total = ge_add(total, lds[0]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) result[blockIdx.x] = total;
+}
+
+}  // namespace bpg

@@ -8,7 +8,7 @@
 
 namespace bpg {
 
-struct scm { uint32_t v[8]; };    // Montgomery form
+struct alignas(16) scm { uint32_t v[8]; };    // Montgomery form
 
 #define BPG_SCM(w0, w1, w2, w3, w4, w5, w6, w7) scm{{w0, w1, w2, w3, w4, w5, w6, w7}}
 BPG_HD scm SC_L() { return BPG_SCM(0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u); }

@@ -1,0 +1,165 @@
+// Host-side Fiat-Shamir transcript (product code): Keccak-f[1600] -> STROBE-128 -> Merlin v1.0 -> TranscriptRng.
+// Mirrors merlin::Transcript as the reference drives it (src/bin/prover.rs:52 Transcript::new(filename),
+// src/cs_buffer.rs:90-92 transcript()), plus the labels of dalek bulletproofs' TranscriptProtocol.
+// The transcript stays on the host: the prover's challenge chain is serial and each step is ~1 us, while the
+// 2n+8 TranscriptRng draws of one proof (one permutation per 64-byte draw) are the only sizeable serial cost and
+// are overlapped with the A_I/A_O multiscalar kernels (see engine.hip).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include "scalar.hpp"
+
+namespace bpg {
+
+static inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// Keccak-f[1600], fully unrolled round body on 25 lane variables.
+static inline void keccak_f1600_host(uint64_t s[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    uint64_t a00 = s[0], a01 = s[1], a02 = s[2], a03 = s[3], a04 = s[4], a05 = s[5], a06 = s[6], a07 = s[7], a08 = s[8], a09 = s[9],
+             a10 = s[10], a11 = s[11], a12 = s[12], a13 = s[13], a14 = s[14], a15 = s[15], a16 = s[16], a17 = s[17], a18 = s[18],
+             a19 = s[19], a20 = s[20], a21 = s[21], a22 = s[22], a23 = s[23], a24 = s[24];
+    for (int r = 0; r < 24; r++) {
+        uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21, c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22,
+                 c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23, c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
+        uint64_t d0 = c4 ^ rotl64(c1, 1), d1 = c0 ^ rotl64(c2, 1), d2 = c1 ^ rotl64(c3, 1), d3 = c2 ^ rotl64(c4, 1), d4 = c3 ^ rotl64(c0, 1);
+        // theta + rho + pi : b[y][2x+3y] = rot(a[x][y])
+        uint64_t b00 = a00 ^ d0, b01 = rotl64(a06 ^ d1, 44), b02 = rotl64(a12 ^ d2, 43), b03 = rotl64(a18 ^ d3, 21), b04 = rotl64(a24 ^ d4, 14);
+        uint64_t b05 = rotl64(a03 ^ d3, 28), b06 = rotl64(a09 ^ d4, 20), b07 = rotl64(a10 ^ d0, 3), b08 = rotl64(a16 ^ d1, 45), b09 = rotl64(a22 ^ d2, 61);
+        uint64_t b10 = rotl64(a01 ^ d1, 1), b11 = rotl64(a07 ^ d2, 6), b12 = rotl64(a13 ^ d3, 25), b13 = rotl64(a19 ^ d4, 8), b14 = rotl64(a20 ^ d0, 18);
+        uint64_t b15 = rotl64(a04 ^ d4, 27), b16 = rotl64(a05 ^ d0, 36), b17 = rotl64(a11 ^ d1, 10), b18 = rotl64(a17 ^ d2, 15), b19 = rotl64(a23 ^ d3, 56);
+        uint64_t b20 = rotl64(a02 ^ d2, 62), b21 = rotl64(a08 ^ d3, 55), b22 = rotl64(a14 ^ d4, 39), b23 = rotl64(a15 ^ d0, 41), b24 = rotl64(a21 ^ d1, 2);
+        // chi
+        a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
+        a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
+        a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
+        a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
+        a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
+        a00 ^= RC[r];
+    }
+    s[0] = a00; s[1] = a01; s[2] = a02; s[3] = a03; s[4] = a04; s[5] = a05; s[6] = a06; s[7] = a07; s[8] = a08; s[9] = a09;
+    s[10] = a10; s[11] = a11; s[12] = a12; s[13] = a13; s[14] = a14; s[15] = a15; s[16] = a16; s[17] = a17; s[18] = a18; s[19] = a19;
+    s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
+}
+
+// SHAKE256 squeeze helper for the generator chains, and SHA3-512 for the Pedersen blinding base.
+class Shake256 {
+public:
+    Shake256() { std::memset(st_, 0, sizeof st_); pos_ = 0; squeezing_ = false; }
+    void absorb(const uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { b[pos_++] ^= d[i]; if (pos_ == 136) { keccak_f1600_host(st_); pos_ = 0; } } }
+    void squeeze(uint8_t *out, size_t n) {
+        uint8_t *b = bytes();
+        if (!squeezing_) { b[pos_] ^= 0x1f; b[135] ^= 0x80; keccak_f1600_host(st_); pos_ = 0; squeezing_ = true; }
+        for (size_t i = 0; i < n; i++) { if (pos_ == 136) { keccak_f1600_host(st_); pos_ = 0; } out[i] = b[pos_++]; }
+    }
+private:
+    uint8_t *bytes() { return reinterpret_cast<uint8_t *>(st_); }
+    uint64_t st_[25]; size_t pos_; bool squeezing_;
+};
+
+static inline void sha3_512_host(uint8_t out[64], const uint8_t *in, size_t n) {
+    uint64_t st[25]; std::memset(st, 0, sizeof st); uint8_t *b = reinterpret_cast<uint8_t *>(st); size_t pos = 0;
+    for (size_t i = 0; i < n; i++) { b[pos++] ^= in[i]; if (pos == 72) { keccak_f1600_host(st); pos = 0; } }
+    b[pos] ^= 0x06; b[71] ^= 0x80; keccak_f1600_host(st); std::memcpy(out, st, 64);
+}
+
+// STROBE-128 restricted to the operations Merlin uses. The 203-byte wire image (200 state bytes, pos, pos_begin,
+// cur_flags) is what crosses the C ABI (include/bpg.h: transcript_state).
+class Strobe128 {
+public:
+    static constexpr int R = 166;
+    enum : uint8_t { FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32 };
+    Strobe128() { std::memset(st_, 0, sizeof st_); pos_ = pos_begin_ = cur_flags_ = 0; }
+    explicit Strobe128(const char *proto) : Strobe128() {
+        uint8_t *b = bytes();
+        const uint8_t hdr[6] = {1, R + 2, 1, 0, 1, 96};
+        std::memcpy(b, hdr, 6); std::memcpy(b + 6, "STROBEv1.0.2", 12);
+        keccak_f1600_host(st_);
+        meta_ad(reinterpret_cast<const uint8_t *>(proto), std::strlen(proto), false);
+    }
+    void meta_ad(const uint8_t *d, size_t n, bool more) { begin_op(FLAG_M | FLAG_A, more); absorb(d, n); }
+    void ad(const uint8_t *d, size_t n, bool more) { begin_op(FLAG_A, more); absorb(d, n); }
+    void prf(uint8_t *d, size_t n, bool more) { begin_op(FLAG_I | FLAG_A | FLAG_C, more); squeeze(d, n); }
+    void key(const uint8_t *d, size_t n, bool more) { begin_op(FLAG_A | FLAG_C, more); overwrite(d, n); }
+    void export_state(uint8_t out[203]) const { std::memcpy(out, st_, 200); out[200] = pos_; out[201] = pos_begin_; out[202] = cur_flags_; }
+    void import_state(const uint8_t in[203]) { std::memcpy(st_, in, 200); pos_ = in[200]; pos_begin_ = in[201]; cur_flags_ = in[202]; }
+private:
+    uint8_t *bytes() { return reinterpret_cast<uint8_t *>(st_); }
+    void run_f() { uint8_t *b = bytes(); b[pos_] ^= pos_begin_; b[pos_ + 1] ^= 0x04; b[R + 1] ^= 0x80; keccak_f1600_host(st_); pos_ = 0; pos_begin_ = 0; }
+    void absorb(const uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { b[pos_++] ^= d[i]; if (pos_ == R) run_f(); } }
+    void overwrite(const uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { b[pos_++] = d[i]; if (pos_ == R) run_f(); } }
+    void squeeze(uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { d[i] = b[pos_]; b[pos_++] = 0; if (pos_ == R) run_f(); } }
+    void begin_op(uint8_t flags, bool more) {
+        if (more) return;
+        uint8_t old = pos_begin_;
+        pos_begin_ = static_cast<uint8_t>(pos_ + 1); cur_flags_ = flags;
+        const uint8_t hdr[2] = {old, flags};
+        absorb(hdr, 2);
+        if ((flags & (FLAG_C | FLAG_K)) && pos_ != 0) run_f();
+    }
+    uint64_t st_[25]; uint8_t pos_, pos_begin_, cur_flags_;
+};
+
+class TranscriptRng {
+public:
+    explicit TranscriptRng(const Strobe128 &s) : s_(s) {}
+    void fill_bytes(uint8_t *dest, size_t n) { uint8_t l4[4]; le32(l4, n); s_.meta_ad(l4, 4, false); s_.prf(dest, n, false); }
+    Scalar random_scalar() { uint8_t b[64]; fill_bytes(b, 64); return Scalar::from_wide(b); }
+    static void le32(uint8_t b[4], size_t n) { b[0] = (uint8_t)n; b[1] = (uint8_t)(n >> 8); b[2] = (uint8_t)(n >> 16); b[3] = (uint8_t)(n >> 24); }
+private:
+    Strobe128 s_;
+};
+
+class Transcript {
+public:
+    Transcript() {}
+    Transcript(const uint8_t *label, size_t n) : s_("Merlin v1.0") { append_message("dom-sep", label, n); }
+    explicit Transcript(const std::string &label) : Transcript(reinterpret_cast<const uint8_t *>(label.data()), label.size()) {}
+    static Transcript from_state(const uint8_t st[203]) { Transcript t; t.s_.import_state(st); return t; }
+    void export_state(uint8_t out[203]) const { s_.export_state(out); }
+
+    void append_message(const char *label, const uint8_t *msg, size_t n) {
+        uint8_t l4[4]; TranscriptRng::le32(l4, n);
+        s_.meta_ad(reinterpret_cast<const uint8_t *>(label), std::strlen(label), false);
+        s_.meta_ad(l4, 4, true);
+        s_.ad(msg, n, false);
+    }
+    void append_u64(const char *label, uint64_t v) { uint8_t b[8]; for (int i = 0; i < 8; i++) b[i] = (uint8_t)(v >> (8 * i)); append_message(label, b, 8); }
+    void challenge_bytes(const char *label, uint8_t *out, size_t n) {
+        uint8_t l4[4]; TranscriptRng::le32(l4, n);
+        s_.meta_ad(reinterpret_cast<const uint8_t *>(label), std::strlen(label), false);
+        s_.meta_ad(l4, 4, true);
+        s_.prf(out, n, false);
+    }
+    // dalek bulletproofs TranscriptProtocol
+    void r1cs_domain_sep() { append_message("dom-sep", reinterpret_cast<const uint8_t *>("r1cs v1"), 7); }
+    void r1cs_1phase_domain_sep() { append_message("dom-sep", reinterpret_cast<const uint8_t *>("r1cs-1phase"), 11); }
+    void innerproduct_domain_sep(uint64_t n) { append_message("dom-sep", reinterpret_cast<const uint8_t *>("ipp v1"), 6); append_u64("n", n); }
+    void append_scalar(const char *label, const Scalar &s) { append_message(label, s.as_bytes(), 32); }
+    void append_point(const char *label, const uint8_t p[32]) { append_message(label, p, 32); }
+    Scalar challenge_scalar(const char *label) { uint8_t b[64]; challenge_bytes(label, b, 64); return Scalar::from_wide(b); }
+
+    // build_rng().rekey_with_witness_bytes("v_blinding", ..)*.finalize(seed)
+    TranscriptRng build_rng(const std::vector<Scalar> &v_blinding, const uint8_t seed[32]) const {
+        Strobe128 s = s_;
+        for (const Scalar &vb : v_blinding) {
+            uint8_t l4[4]; TranscriptRng::le32(l4, 32);
+            s.meta_ad(reinterpret_cast<const uint8_t *>("v_blinding"), 10, false);
+            s.meta_ad(l4, 4, true);
+            s.key(vb.as_bytes(), 32, false);
+        }
+        s.meta_ad(reinterpret_cast<const uint8_t *>("rng"), 3, false);
+        s.key(seed, 32, false);
+        return TranscriptRng(s);
+    }
+private:
+    Strobe128 s_;
+};
+
+}  // namespace bpg

@@ -1,0 +1,214 @@
+// Host-side constraint-system surface (product code, C++), mirroring bulletproofs::r1cs as the reference uses it:
+//   Variable / LinearCombination                       src/bin/prover.rs:8,245 ; src/conversions.rs:49-64
+//   trait ConstraintSystem {multiply, allocate, allocate_multiplier, constrain}   src/cs_buffer.rs:89-113
+//   Prover::{new, commit, num_constraints, get_num_multiplications, prove}        src/bin/prover.rs:54,89,92-93
+//   Verifier::{new, commit, get_num_vars}                                         src/bin/verifier.rs:51-53,89
+// Assembly (witness synthesis, LC evaluation, constraint list) stays on the host exactly as in the reference; only
+// commit() and prove() cross the C ABI into the HIP engine.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+#include "scalar.hpp"
+#include "merlin.hpp"
+
+namespace bpg {
+
+struct Variable {
+    enum Kind : uint32_t { MultiplierLeft = 0, MultiplierRight = 1, MultiplierOutput = 2, Committed = 3, One = 4 };
+    Kind kind; uint32_t idx;
+    static Variable one() { return Variable{One, 0}; }
+    uint32_t packed() const { return (static_cast<uint32_t>(kind) << 29) | idx; }
+    static Variable unpack(uint32_t p) { return Variable{static_cast<Kind>(p >> 29), p & 0x1fffffffu}; }
+};
+
+struct LinearCombination {
+    std::vector<std::pair<Variable, Scalar>> terms;
+    LinearCombination() {}
+    LinearCombination(const Variable &v) { terms.emplace_back(v, Scalar::one()); }          // From<Variable>
+    LinearCombination(const Scalar &s) { terms.emplace_back(Variable::one(), s); }           // From<Scalar>
+    LinearCombination operator+(const LinearCombination &o) const { LinearCombination r = *this; r.terms.insert(r.terms.end(), o.terms.begin(), o.terms.end()); return r; }
+    LinearCombination operator-(const LinearCombination &o) const { LinearCombination r = *this; for (auto &t : o.terms) r.terms.emplace_back(t.first, -t.second); return r; }
+    LinearCombination operator-() const { LinearCombination r; for (auto &t : terms) r.terms.emplace_back(t.first, -t.second); return r; }
+    LinearCombination operator*(const Scalar &s) const { LinearCombination r; for (auto &t : terms) r.terms.emplace_back(t.first, t.second * s); return r; }
+};
+
+enum class R1CSError { None = 0, InvalidGeneratorsLength = 1, FormatError = 2, VerificationError = 3, MissingAssignment = 5, GadgetError = 6 };
+struct R1CSException : std::runtime_error {
+    R1CSError code;
+    R1CSException(R1CSError c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+struct OptScalar { bool some; Scalar v; OptScalar() : some(false) {} OptScalar(const Scalar &s) : some(true), v(s) {} };
+struct MulVars { Variable l, r, o; };
+
+class ConstraintSystem {
+public:
+    virtual ~ConstraintSystem() {}
+    virtual MulVars multiply(LinearCombination left, LinearCombination right) = 0;
+    virtual Variable allocate(const OptScalar &assignment) = 0;
+    virtual MulVars allocate_multiplier(bool some, const Scalar &l, const Scalar &r) = 0;
+    virtual void constrain(const LinearCombination &lc) = 0;
+};
+
+// Flattened instance handed to the engine / exported for the oracle (layout of include/bpg.h bpg_r1cs_upload)
+struct FlatCircuit {
+    uint64_t n = 0, m = 0;
+    std::vector<uint8_t> aL, aR, aO;             // n*32 each (empty on the verifier side)
+    std::vector<uint64_t> row_ptr{0};
+    std::vector<uint32_t> term_var, term_coef;
+    std::vector<uint8_t> coef;                   // ncoef*32, deduplicated coefficient table
+};
+
+// Shared bookkeeping of Prover and Verifier: constraint rows with a coefficient dictionary.
+class CircuitCore {
+protected:
+    struct KeyHash { size_t operator()(const Scalar &s) const { return (size_t)(s.w[0] * 0x9e3779b97f4a7c15ULL ^ s.w[1] ^ (s.w[2] << 1) ^ (s.w[3] >> 3)); } };
+    std::vector<uint64_t> row_ptr_{0};
+    std::vector<uint32_t> term_var_, term_coef_;
+    std::vector<Scalar> coef_;
+    std::unordered_map<Scalar, uint32_t, KeyHash> coef_index_;
+    void push_row(const LinearCombination &lc) {
+        for (auto &t : lc.terms) {
+            Scalar c = t.second.is_canonical() ? t.second : t.second.reduced();
+            auto it = coef_index_.find(c);
+            uint32_t id;
+            if (it == coef_index_.end()) { id = (uint32_t)coef_.size(); coef_.push_back(c); coef_index_.emplace(c, id); } else id = it->second;
+            term_var_.push_back(t.first.packed()); term_coef_.push_back(id);
+        }
+        row_ptr_.push_back(term_var_.size());
+    }
+    void export_rows(FlatCircuit &f) const {
+        f.row_ptr = row_ptr_; f.term_var = term_var_; f.term_coef = term_coef_;
+        f.coef.resize(coef_.size() * 32);
+        for (size_t i = 0; i < coef_.size(); i++) coef_[i].to_bytes(&f.coef[32 * i]);
+    }
+public:
+    size_t num_constraints() const { return row_ptr_.size() - 1; }
+};
+
+class Engine;   // engine.hip
+
+class Prover : public ConstraintSystem, public CircuitCore {
+public:
+    // Prover::new(&pc_gens, &mut transcript): the transcript is borrowed for the prover's lifetime
+    Prover(Engine *engine, Transcript *transcript) : engine_(engine), t_(transcript) { t_->r1cs_domain_sep(); }
+
+    // Prover::commit(v, v_blinding) -> (CompressedRistretto, Variable)
+    std::pair<std::vector<uint8_t>, Variable> commit(const Scalar &v, const Scalar &v_blinding);
+    // batched form of the same call sequence (identical transcript effect, one kernel launch)
+    std::vector<Variable> commit_many(const std::vector<Scalar> &v, const std::vector<Scalar> &blind, std::vector<uint8_t> &coms_out);
+
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        Scalar l = eval(left), r = eval(right), o = l * r;
+        uint32_t i = (uint32_t)aL_.size();
+        MulVars mv{{Variable::MultiplierLeft, i}, {Variable::MultiplierRight, i}, {Variable::MultiplierOutput, i}};
+        aL_.push_back(l); aR_.push_back(r); aO_.push_back(o);
+        left.terms.emplace_back(mv.l, -Scalar::one());
+        right.terms.emplace_back(mv.r, -Scalar::one());
+        constrain(left); constrain(right);
+        return mv;
+    }
+    Variable allocate(const OptScalar &a) override {
+        if (!a.some) throw R1CSException(R1CSError::MissingAssignment, "missing assignment");
+        if (pending_ < 0) {
+            uint32_t i = (uint32_t)aL_.size(); pending_ = i;
+            aL_.push_back(a.v); aR_.push_back(Scalar::zero()); aO_.push_back(Scalar::zero());
+            return Variable{Variable::MultiplierLeft, i};
+        }
+        uint32_t i = (uint32_t)pending_; pending_ = -1;
+        aR_[i] = a.v; aO_[i] = aL_[i] * aR_[i];
+        return Variable{Variable::MultiplierRight, i};
+    }
+    MulVars allocate_multiplier(bool some, const Scalar &l, const Scalar &r) override {
+        if (!some) throw R1CSException(R1CSError::MissingAssignment, "missing assignment");
+        uint32_t i = (uint32_t)aL_.size();
+        aL_.push_back(l); aR_.push_back(r); aO_.push_back(l * r);
+        return MulVars{{Variable::MultiplierLeft, i}, {Variable::MultiplierRight, i}, {Variable::MultiplierOutput, i}};
+    }
+    void constrain(const LinearCombination &lc) override { push_row(lc); }
+
+    size_t get_num_multiplications() const { return aL_.size(); }
+    size_t num_committed() const { return v_.size(); }
+    const std::vector<Scalar> &v() const { return v_; }
+    const std::vector<Scalar> &v_blinding() const { return vb_; }
+    Transcript *transcript() { return t_; }
+
+    Scalar eval(const LinearCombination &lc) const {
+        Scalar acc;
+        for (auto &t : lc.terms) {
+            const Scalar *x;
+            static const Scalar ONE = Scalar::one();
+            switch (t.first.kind) {
+            case Variable::MultiplierLeft: x = &aL_[t.first.idx]; break;
+            case Variable::MultiplierRight: x = &aR_[t.first.idx]; break;
+            case Variable::MultiplierOutput: x = &aO_[t.first.idx]; break;
+            case Variable::Committed: x = &v_[t.first.idx]; break;
+            default: x = &ONE; break;
+            }
+            acc += t.second * *x;
+        }
+        return acc;
+    }
+
+    FlatCircuit flatten() const {
+        FlatCircuit f; f.n = aL_.size(); f.m = v_.size();
+        f.aL.resize(f.n * 32); f.aR.resize(f.n * 32); f.aO.resize(f.n * 32);
+        for (size_t i = 0; i < f.n; i++) { red(aL_[i]).to_bytes(&f.aL[32 * i]); red(aR_[i]).to_bytes(&f.aR[32 * i]); red(aO_[i]).to_bytes(&f.aO[32 * i]); }
+        export_rows(f);
+        return f;
+    }
+
+    // Prover::prove(&bp_gens) -> R1CSProof::to_bytes(). rng_seed replaces thread_rng() (32 external bytes).
+    std::vector<uint8_t> prove(uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags);
+
+private:
+    static Scalar red(const Scalar &s) { return s.is_canonical() ? s : s.reduced(); }
+    Engine *engine_;
+    Transcript *t_;
+    std::vector<Scalar> aL_, aR_, aO_, v_, vb_;
+    int64_t pending_ = -1;
+};
+
+class Verifier : public ConstraintSystem, public CircuitCore {
+public:
+    explicit Verifier(Transcript *transcript) : t_(transcript) { t_->r1cs_domain_sep(); }
+    // Verifier::commit(CompressedRistretto) -> Variable
+    Variable commit(const uint8_t com[32]) {
+        uint32_t i = (uint32_t)(V_.size() / 32);
+        V_.insert(V_.end(), com, com + 32);
+        t_->append_point("V", com);
+        return Variable{Variable::Committed, i};
+    }
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        uint32_t i = (uint32_t)num_vars_++;
+        MulVars mv{{Variable::MultiplierLeft, i}, {Variable::MultiplierRight, i}, {Variable::MultiplierOutput, i}};
+        left.terms.emplace_back(mv.l, -Scalar::one());
+        right.terms.emplace_back(mv.r, -Scalar::one());
+        constrain(left); constrain(right);
+        return mv;
+    }
+    Variable allocate(const OptScalar &) override {
+        if (pending_ < 0) { pending_ = (int64_t)num_vars_++; return Variable{Variable::MultiplierLeft, (uint32_t)pending_}; }
+        uint32_t i = (uint32_t)pending_; pending_ = -1; return Variable{Variable::MultiplierRight, i};
+    }
+    MulVars allocate_multiplier(bool, const Scalar &, const Scalar &) override {
+        uint32_t i = (uint32_t)num_vars_++;
+        return MulVars{{Variable::MultiplierLeft, i}, {Variable::MultiplierRight, i}, {Variable::MultiplierOutput, i}};
+    }
+    void constrain(const LinearCombination &lc) override { push_row(lc); }
+    size_t get_num_vars() const { return num_vars_; }
+    const std::vector<uint8_t> &commitments() const { return V_; }
+    Transcript *transcript() { return t_; }
+    FlatCircuit flatten() const { FlatCircuit f; f.n = num_vars_; f.m = V_.size() / 32; export_rows(f); return f; }
+private:
+    Transcript *t_;
+    std::vector<uint8_t> V_;
+    size_t num_vars_ = 0;
+    int64_t pending_ = -1;
+};
+
+}  // namespace bpg

@@ -1,0 +1,158 @@
+/* bpg.h - C ABI of the MI355X-native Bulletproofs R1CS prove path (libbpg_hip.so).
+ *
+ * Drop-in boundary for MarcKloter/bulletproofs_gadgets: the reference reaches this path through Rust crates
+ * (bulletproofs fork, curve25519-dalek, merlin; reference Cargo.toml:8-20) that have no FFI today.  A Rust host
+ * keeps the mini-language parser and the R1CS assembly and binds the functions of PART 1 (see INTEGRATION.md for
+ * the `extern "C"` block); PART 2 is the same assembly surface offered natively (C++ inside the library) for hosts
+ * without a Rust toolchain - the repo's Python harness, tests and bench.py drive it through ctypes.
+ *
+ * Conventions: scalars and compressed points are 32-byte little-endian encodings; the caller allocates every
+ * output; every function returns a bpg_status (0 = ok) and never unwinds across the boundary; a context (and the
+ * objects created from it) is used by one host thread at a time, different contexts are independent.
+ * There is NO CPU fallback: bpg_ctx_create fails with BPG_ERR_DEVICE when no AMD GPU is visible.
+ */
+#ifndef BPG_H
+#define BPG_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t bpg_status;
+#define BPG_OK 0
+#define BPG_ERR_INVALID_GENERATORS_LENGTH 1   /* R1CSError::InvalidGeneratorsLength */
+#define BPG_ERR_FORMAT 2                      /* R1CSError::FormatError */
+#define BPG_ERR_VERIFICATION 3                /* R1CSError::VerificationError */
+#define BPG_ERR_INVALID_ARGUMENT 4
+#define BPG_ERR_MISSING_ASSIGNMENT 5          /* R1CSError::MissingAssignment (reference src/cs_buffer.rs:104) */
+#define BPG_ERR_GADGET 6                      /* R1CSError::GadgetError        (reference src/cs_buffer.rs:100) */
+#define BPG_ERR_DEVICE 7
+#define BPG_ERR_INTERNAL 8
+
+/* dialect flags of the proof encoding / transcript (the fork's revision is unpinned) */
+#define BPG_FLAG_COMPACT_1PHASE 1u            /* v2.0.0 encoding: version byte 0x00 + 11 points */
+#define BPG_FLAG_NO_1PHASE_DOMSEP 2u          /* omit the "r1cs-1phase" domain separator */
+
+/* variable encoding inside constraint terms: kind << 29 | index   (bulletproofs::r1cs::Variable) */
+#define BPG_VAR_MULTIPLIER_LEFT 0u
+#define BPG_VAR_MULTIPLIER_RIGHT 1u
+#define BPG_VAR_MULTIPLIER_OUTPUT 2u
+#define BPG_VAR_COMMITTED 3u
+#define BPG_VAR_ONE 4u
+#define BPG_TRANSCRIPT_STATE_BYTES 203        /* STROBE-128: 200 state bytes, pos, pos_begin, cur_flags */
+
+typedef struct bpg_ctx bpg_ctx;
+typedef struct bpg_circuit bpg_circuit;
+
+/* Flattened R1CS instance = the state a bulletproofs::r1cs::Prover holds when prove() is called:
+ * a_L, a_R, a_O (n x 32 B, reduced mod l) and the constraint list in CSR form with a de-duplicated coefficient table. */
+typedef struct {
+    uint64_t n, q, m, nnz, ncoef;
+    const uint8_t *aL, *aR, *aO;
+    const uint64_t *row_ptr;      /* q + 1 */
+    const uint32_t *term_var;     /* nnz : kind << 29 | index */
+    const uint32_t *term_coef;    /* nnz : index into coef */
+    const uint8_t *coef;          /* ncoef x 32 */
+} bpg_r1cs_instance;
+
+typedef struct {                  /* milliseconds; filled when a non-NULL pointer is passed to a prove call */
+    double rng_host, msm_aiao, msm_s, poly, ipa, total, ipa_msm, ipa_fold, ipa_sync;
+} bpg_timings;
+
+/* ---------------------------------------------------------------------------------------------------- PART 1: hot path */
+const char *bpg_strerror(bpg_status s);
+const char *bpg_last_error(void);                                /* message of the calling thread's last failure */
+
+/* replaces PedersenGens::default() + device selection            (reference src/bin/prover.rs:53) */
+bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out);
+void bpg_ctx_destroy(bpg_ctx *ctx);
+bpg_status bpg_pedersen_bases(bpg_ctx *ctx, uint8_t B[32], uint8_t B_blinding[32]);
+
+/* replaces BulletproofGens::new(capacity, 1)                     (reference src/bin/prover.rs:92); tables stay in HBM */
+bpg_status bpg_gens_ensure(bpg_ctx *ctx, uint64_t capacity);
+bpg_status bpg_gens_export(bpg_ctx *ctx, uint64_t first, uint64_t count, uint8_t *G_out, uint8_t *H_out);
+
+/* replaces the point part of Prover::commit(v, v_blinding)       (reference src/gadget.rs:31, src/commitments.rs:27,39):
+ * out[i] = compress(v[i]*B + blind[i]*B_blinding); v may be an unreduced Scalar::from_bits value */
+bpg_status bpg_pedersen_commit(bpg_ctx *ctx, uint64_t k, const uint8_t *v, const uint8_t *blind, uint8_t *out);
+
+/* replaces Prover::prove(&bp_gens) + R1CSProof::to_bytes()        (reference src/bin/prover.rs:93,97).
+ * transcript_state: Merlin state after Transcript::new(label), Prover::new and every "V" append; updated in place.
+ * rng_seed replaces the 32 bytes upstream draws from thread_rng(). proof_len: in = capacity, out = bytes written. */
+bpg_status bpg_r1cs_upload(bpg_ctx *ctx, const bpg_r1cs_instance *inst, bpg_circuit **out);
+void bpg_r1cs_free(bpg_ctx *ctx, bpg_circuit *c);
+bpg_status bpg_r1cs_prove_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
+                                   uint64_t m, const uint8_t *v_blinding, const uint8_t rng_seed[32], uint32_t flags,
+                                   uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);
+bpg_status bpg_r1cs_prove(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
+                          uint64_t m, const uint8_t *v_blinding, const uint8_t rng_seed[32], uint32_t flags,
+                          uint8_t *proof_out, uint64_t *proof_len);
+uint64_t bpg_proof_size(uint64_t n_multipliers, uint32_t flags);
+
+/* test hook: compress(sum s_i*G[first+i] + t_i*H[first+i]) through the bucket-method MSM kernels */
+bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
+
+/* ---------------------------------------------------------------------------------------------------- PART 2: host mirror
+ * merlin::Transcript, bulletproofs::r1cs::{Prover, Verifier}, and the reference's Gadget trait with BoundsCheck,
+ * MimcHash256 and MerkleTree256 (reference src/gadget.rs:6-59 and the gadget modules), implemented in C++. */
+typedef struct bpg_transcript bpg_transcript;
+typedef struct bpg_prover bpg_prover;
+typedef struct bpg_verifier bpg_verifier;
+typedef struct bpg_gadget bpg_gadget;
+typedef struct { uint32_t var; uint8_t coeff[32]; } bpg_term;       /* (Variable, Scalar); var = kind << 29 | index */
+typedef struct { const bpg_term *terms; uint64_t n; } bpg_lc;        /* bulletproofs::r1cs::LinearCombination */
+
+bpg_status bpg_transcript_new(const uint8_t *label, uint64_t len, bpg_transcript **out);        /* Transcript::new */
+void bpg_transcript_free(bpg_transcript *t);
+bpg_status bpg_transcript_append_message(bpg_transcript *t, const char *label, const uint8_t *msg, uint64_t len);
+bpg_status bpg_transcript_challenge_bytes(bpg_transcript *t, const char *label, uint8_t *out, uint64_t len);
+bpg_status bpg_transcript_state(const bpg_transcript *t, uint8_t out[BPG_TRANSCRIPT_STATE_BYTES]);
+
+bpg_status bpg_prover_new(bpg_ctx *ctx, bpg_transcript *t, bpg_prover **out);                   /* Prover::new */
+void bpg_prover_free(bpg_prover *p);
+bpg_status bpg_prover_commit(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], uint8_t com_out[32], uint32_t *var_out);
+bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, const uint8_t *blind, uint8_t *coms_out, uint32_t *vars_out);
+uint64_t bpg_prover_num_constraints(const bpg_prover *p);                                       /* fork getter, prover.rs:89 */
+uint64_t bpg_prover_num_multiplications(const bpg_prover *p);                                   /* fork getter, prover.rs:92 */
+uint64_t bpg_prover_num_committed(const bpg_prover *p);
+/* ConstraintSystem methods (trait visible at reference src/cs_buffer.rs:89-113) */
+bpg_status bpg_prover_multiply(bpg_prover *p, const bpg_lc *left, const bpg_lc *right, uint32_t vars_out[3]);
+bpg_status bpg_prover_allocate_multiplier(bpg_prover *p, int32_t has_assignment, const uint8_t l[32], const uint8_t r[32], uint32_t vars_out[3]);
+bpg_status bpg_prover_allocate(bpg_prover *p, int32_t has_assignment, const uint8_t s[32], uint32_t *var_out);
+bpg_status bpg_prover_constrain(bpg_prover *p, const bpg_lc *lc);
+/* borrowed view of the assembled instance (valid until the prover is next mutated or freed) */
+bpg_status bpg_prover_instance(bpg_prover *p, bpg_r1cs_instance *out, const uint8_t **v_out, const uint8_t **v_blinding_out);
+bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags,
+                            uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);
+
+bpg_status bpg_verifier_new(bpg_transcript *t, bpg_verifier **out);                             /* Verifier::new */
+void bpg_verifier_free(bpg_verifier *v);
+bpg_status bpg_verifier_commit(bpg_verifier *v, const uint8_t com[32], uint32_t *var_out);       /* Verifier::commit */
+uint64_t bpg_verifier_num_vars(const bpg_verifier *v);                                          /* fork getter, verifier.rs:89 */
+bpg_status bpg_verifier_instance(bpg_verifier *v, bpg_r1cs_instance *out, const uint8_t **commitments_out);
+
+bpg_status bpg_bounds_check_new(const uint8_t *min_be, uint64_t min_len, const uint8_t *max_be, uint64_t max_len, bpg_gadget **out);
+bpg_status bpg_mimc_hash256_new(const bpg_lc *image, bpg_gadget **out);
+bpg_status bpg_merkle_tree256_new(const bpg_lc *root, const bpg_lc *instance_vars, uint64_t n_inst, const bpg_lc *witness_vars,
+                                  uint64_t n_wit, const char *pattern, bpg_gadget **out);
+void bpg_gadget_free(bpg_gadget *g);
+/* Gadget::setup: derived = preprocess(witnesses); one commitment each. *n_derived: in = capacity, out = count */
+bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *witness_scalars, uint64_t n_wit, const uint8_t *blindings,
+                            uint64_t n_blind, uint8_t *coms_out, uint8_t *derived_scalars_out, uint32_t *derived_vars_out, uint64_t *n_derived);
+bpg_status bpg_gadget_prove(bpg_gadget *g, bpg_prover *p, const uint32_t *vars, uint64_t n_vars, const uint8_t *derived_scalars,
+                            const uint32_t *derived_vars, uint64_t n_derived);
+bpg_status bpg_gadget_verify(bpg_gadget *g, bpg_verifier *v, const uint32_t *vars, uint64_t n_vars, const uint32_t *derived_vars, uint64_t n_derived);
+/* utils::range_proof(cs, x, n, x_assignment) on a prover (assignment given) or a verifier (none) */
+bpg_status bpg_range_proof_prove(bpg_prover *p, const bpg_lc *x, uint32_t n_bits, const uint8_t assignment[32]);
+bpg_status bpg_range_proof_verify(bpg_verifier *v, const bpg_lc *x, uint32_t n_bits);
+/* mimc::mimc_hash(preimage) -> Scalar bytes (little-endian); conversions */
+bpg_status bpg_mimc_hash(const uint8_t *preimage, uint64_t len, uint8_t out[32]);
+bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint64_t *n_out);   /* conversions::be_to_scalars */
+/* host scalar arithmetic (curve25519_dalek::Scalar semantics), exposed for tests: op 0 add, 1 sub, 2 mul, 3 invert, 4 reduce, 5 from_wide(a = 64 B) */
+bpg_status bpg_scalar_op(int32_t op, const uint8_t *a, const uint8_t *b, uint8_t out[32]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

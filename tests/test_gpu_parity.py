@@ -1,0 +1,280 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libbpg_hip.so and is
+compared byte for byte with the CPU oracle on the same seeded inputs, then checked by the oracle's verifier."""
+import hashlib
+import pytest
+import bulletproofs_gadgets_amd as bpg
+from bulletproofs_gadgets_amd import workloads
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+sc = lambda x: (x % R.L).to_bytes(32, "little")
+rs = lambda tag, i: sc(int.from_bytes(hashlib.sha512(b"%s%d" % (tag, i)).digest(), "little"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bpg.Context(0)
+
+
+def to_oracle(inst):
+    return O.FlatCircuit(inst.n, inst.m, inst.aL or None, inst.aR or None, inst.aO or None, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+
+
+def check_against_oracle(ctx, prover, transcript, commitments, capacity, replay=None, flags_list=(0,), seed=bytes(range(32)), ogens=None):
+    """prove on the GPU for each dialect; compare with the oracle; verify with the oracle on the VERIFIER-side circuit."""
+    inst = prover.instance()
+    state = transcript.state
+    oc = to_oracle(inst)
+    assert O.satisfied(oc, inst.v)
+    ogens = ogens or O.Gens(capacity)
+    ctx.gens_ensure(capacity)
+    res = ctx.upload(inst)
+    vstate, vcirc = None, None
+    if replay is not None:
+        tv = bpg.Transcript(transcript._label)
+        v = bpg.Verifier(tv)
+        replay(v)
+        vi = v.instance()
+        assert vi.commitments == b"".join(commitments)
+        vstate, vcirc = tv.state, to_oracle(vi)
+        assert vstate == state
+    proofs = []
+    for flags in flags_list:
+        proof, st_after = res.prove(state, inst.v_blinding, seed, flags)
+        rc, want, st_want = O.prove(ogens, state, oc, inst.v_blinding, seed, flags | O.FLAG_FAST_MSM)
+        assert rc == 0
+        assert proof == want, "flags=%d: GPU proof bytes differ from the oracle" % flags
+        assert st_after == st_want
+        assert O.verify(ogens, vstate or state, vcirc or oc, b"".join(commitments), proof, flags=flags) == 0
+        proofs.append(proof)
+    res.free()
+    return proofs
+
+
+class LabeledTranscript(bpg.Transcript):
+    def __init__(self, label):
+        super().__init__(label)
+        self._label = label
+
+
+def test_pedersen_bases_and_commitments(ctx, golden):
+    B, Bb = ctx.pedersen_bases()
+    assert B.hex() == golden["pedersen"]["B"] and Bb.hex() == golden["pedersen"]["B_blinding"]
+    vs = [H(v["v"]) for v in golden["pedersen_commit"]]
+    rr = [H(v["r"]) for v in golden["pedersen_commit"]]
+    assert [c.hex() for c in ctx.pedersen_commit(vs, rr)] == [v["commit"] for v in golden["pedersen_commit"]]
+    vs = [rs(b"pv", i) for i in range(130)] + [bytes(32), b"\xff" * 31 + b"\x7f"]
+    rr = [rs(b"pr", i) for i in range(130)] + [bytes(32), sc(R.L - 1)]
+    got = ctx.pedersen_commit(vs, rr)
+    for v, r, g in zip(vs, rr, got):
+        assert g == O.pedersen_commit(v, r)
+
+
+def test_generators_match_golden_and_oracle(ctx, golden):
+    ctx.gens_ensure(2048)
+    G, Hh = ctx.gens_export(0, 8)
+    assert [G[32 * i:32 * i + 32].hex() for i in range(8)] == golden["bp_gens"]["G"]
+    assert [Hh[32 * i:32 * i + 32].hex() for i in range(8)] == golden["bp_gens"]["H"]
+    og = O.Gens(2048)
+    assert ctx.gens_export(0, 2048) == og.export(0, 2048)
+    ctx.gens_ensure(4096)                      # growing keeps the prefix (GeneratorsChain is a stream)
+    assert ctx.gens_export(1000, 1048) == og.export(1000, 1048)
+    with pytest.raises(bpg.BpgError):
+        ctx.gens_ensure(1000)                  # not a power of two
+
+
+@pytest.mark.parametrize("count", [1, 2, 3, 33, 190, 700, 5000])
+def test_msm_matches_oracle(ctx, count):
+    ctx.gens_ensure(8192)
+    G, Hh = ctx.gens_export(7, count)
+    s = [rs(b"ms", i) for i in range(count)]
+    t = [rs(b"mt", i) for i in range(count)]
+    # edge scalars: zeros, ones (everything lands in one bucket), l-1
+    for i in range(0, count, 5):
+        s[i] = bytes(32)
+    for i in range(1, count, 7):
+        t[i] = sc(1)
+    if count > 2:
+        s[2] = sc(R.L - 1)
+    want = O.msm(b"".join(s + t), G + Hh, 1)
+    assert ctx.msm_gens(7, s, t) == want
+
+
+def test_msm_all_ones_and_all_zero(ctx):
+    ctx.gens_ensure(8192)
+    n = 3000
+    G, Hh = ctx.gens_export(0, n)
+    ones, zeros = [sc(1)] * n, [bytes(32)] * n
+    assert ctx.msm_gens(0, ones, zeros) == O.msm(b"".join(ones), G, 1)          # a single heavy bucket
+    assert ctx.msm_gens(0, zeros, zeros) == bytes(32)                            # identity encodes as zeros
+
+
+def test_tiny_circuits_all_dialects(ctx):
+    # n = 1, 2, 3, 5: padded sizes 1, 2, 4, 8; committed x, y, z with x*y = z
+    for nm in (1, 2, 3, 5):
+        t = LabeledTranscript(b"unit")
+        p = bpg.Prover(ctx, t)
+        coms = []
+        for i in range(nm):
+            x, y = rs(b"x", i), rs(b"y", i)
+            z = bpg.scalar_op("mul", x, y)
+            cs, vs = p.commit_many([x, y, z], [rs(b"bl", 3 * i + k) for k in range(3)])
+            coms += cs
+            l, r, o = p.multiply(vs[0], vs[1])
+            p.constrain(bpg.LinearCombination.of(o) - vs[2])
+        assert p.get_num_multiplications() == nm and p.num_constraints() == 3 * nm
+        check_against_oracle(ctx, p, t, coms, 16, flags_list=(0, 1, 2, 3))
+
+
+def test_constraint_only_circuit_n0(ctx):
+    # no multipliers at all (e.g. the reference's EQUALS gadget): n = 0 pads to N = 1
+    t = LabeledTranscript(b"eq")
+    p = bpg.Prover(ctx, t)
+    x = rs(b"eqv", 0)
+    cs, vs = p.commit_many([x, x], [rs(b"eqb", 0), rs(b"eqb", 1)])
+    p.constrain(bpg.LinearCombination.of(vs[0]) - vs[1])
+    check_against_oracle(ctx, p, t, cs, 1)
+
+
+def test_range_proof_reference_cases(ctx):
+    # reference src/utils.rs:46-90: constant LC, no commitments (m = 0); n = 56 verifies, n = 48 must not
+    x = bpg.be_to_scalar(H("0522a64d7b931e"))
+    for nbits, ok in ((56, True), (48, False)):
+        t = bpg.Transcript(b"RangeProof")
+        p = bpg.Prover(ctx, t)
+        bpg.range_proof(p, x, nbits, x)
+        inst = p.instance()
+        state = t.state
+        proof = p.prove(bpg.BulletproofGens(ctx, 256), bytes(32))
+        og = O.Gens(256)
+        rc, want, _ = O.prove(og, state, to_oracle(inst), b"", bytes(32), O.FLAG_FAST_MSM)
+        assert proof == want
+        tv = bpg.Transcript(b"RangeProof")
+        v = bpg.Verifier(tv)
+        bpg.range_proof(v, x, nbits)
+        assert (O.verify(og, tv.state, to_oracle(v.instance()), b"", proof) == 0) == ok
+
+
+def test_bounds_check_gadget_reference_case(ctx):
+    # reference src/bounds_check/bounds_check_gadget.rs:75-99
+    lo, hi, w = bytes([10]), bytes([100]), bytes([67])
+    t = LabeledTranscript(b"BoundsCheck")
+    p = bpg.Prover(ctx, t)
+    g = bpg.BoundsCheck(lo, hi)
+    scalars, wc, wv = bpg.commit(p, w, [rs(b"bc", 0)])
+    dc, dw = g.setup(p, scalars, [rs(b"bc", 1), rs(b"bc", 2)])
+    g.prove(p, wv, dw)
+
+    def replay(v):
+        g2 = bpg.BoundsCheck(lo, hi)
+        g2.verify(v, bpg.verifier_commit(v, wc), bpg.verifier_commit(v, dc))
+    check_against_oracle(ctx, p, t, wc + dc, 16, replay, flags_list=(0, 1))
+    # out-of-range witness: proof is produced but must not verify
+    t = LabeledTranscript(b"BoundsCheck")
+    p = bpg.Prover(ctx, t)
+    scalars, wc, wv = bpg.commit(p, bytes([101]), [rs(b"bc", 0)])
+    dc, dw = g.setup(p, scalars, [rs(b"bc", 1), rs(b"bc", 2)])
+    g.prove(p, wv, dw)
+    inst, state = p.instance(), t.state
+    proof = p.prove(16, bytes(32))
+    assert O.verify(O.Gens(16), state, to_oracle(inst), b"".join(wc + dc), proof) != 0
+    with pytest.raises(bpg.BpgError) as e:      # capacity below the padded size -> InvalidGeneratorsLength
+        t2 = LabeledTranscript(b"BoundsCheck"); p2 = bpg.Prover(ctx, t2)
+        s2, _, v2 = bpg.commit(p2, w, [rs(b"bc", 0)]); _, d2 = g.setup(p2, s2, [rs(b"bc", 1), rs(b"bc", 2)]); g.prove(p2, v2, d2)
+        p2.prove(8, bytes(32))
+    assert e.value.status == 1
+
+
+def test_cfg2_bounds_check_64(ctx):
+    a = workloads.bounds_check_64(ctx, seed=3, label=b"BoundsCheck")
+    a.transcript._label = b"BoundsCheck"
+    inst = a.prover.instance()
+    assert (inst.n, inst.q, inst.m) == (128, 259, 3)
+    check_against_oracle(ctx, a.prover, a.transcript, a.commitments, 128, a.replay, flags_list=(0, 1, 2, 3))
+
+
+@pytest.mark.parametrize("pre,label", [(H("38535450433043546f313877615a6a423663"), b"MiMCHash"),
+                                        (b"The quick brown fox jumps over t", b"MiMCHash")])
+def test_mimc_hash_gadget_reference_cases(ctx, pre, label):
+    # reference src/mimc_hash/mimc_hash_gadget.rs:163-272 (happy padding case and the extra-block edge case)
+    image = bpg.mimc_hash(pre)
+    t = LabeledTranscript(label)
+    p = bpg.Prover(ctx, t)
+    g = bpg.MimcHash256(image)
+    scalars, wc, wv = bpg.commit(p, pre, [rs(b"mh", i) for i in range(4)])
+    dc, dw = g.setup(p, scalars, [rs(b"mh", 10), rs(b"mh", 11)])
+    g.prove(p, wv, dw)
+
+    def replay(v):
+        bpg.MimcHash256(image).verify(v, bpg.verifier_commit(v, wc), bpg.verifier_commit(v, dc))
+    check_against_oracle(ctx, p, t, wc + dc, 2048, replay)
+    # wrong image must not verify
+    t = LabeledTranscript(label)
+    p = bpg.Prover(ctx, t)
+    bad = bpg.MimcHash256(bpg.mimc_hash(pre + b"x"))
+    scalars, wc, wv = bpg.commit(p, pre, [rs(b"mh", i) for i in range(4)])
+    dc, dw = bad.setup(p, scalars, [rs(b"mh", 10), rs(b"mh", 11)])
+    bad.prove(p, wv, dw)
+    inst, state = p.instance(), t.state
+    proof = p.prove(2048, bytes(32))
+    assert O.verify(O.Gens(2048), state, to_oracle(inst), b"".join(wc + dc), proof) != 0
+
+
+W = {k: H(v) for k, v in {
+    1: "0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb668749", 2: "07faf8aaa21077200a11576b1cdb402f52a47f192b36998b4da25807a9be52f5",
+    3: "09243333e374e76e4975ab48ae38241ba67805cd60f1523e9b79a48daac9a84d", 4: "0258647e47e8005748d4e7d0d76b230cc20f2a0f8745eee2bccced0c2add59d5",
+    5: "011c6fc7f15087f4d3e97e672813af066f74f60446bc75aa85eb2d6db8ae791b", 6: "0f8653b7e734422fc75bdb4eb1bc774cd34f9ab3a89545e021016a4d9171a902",
+    7: "0bd752eb80bfa5189bade1cc8f49cf5fe1843e1ff736367afc52670e429d1c36", 8: "181c63cfc823a477b0825004475222e1c7d060179b6b247ffa5adc58e307de0d",
+    9: "2ad84a04eb9394e0cc4b4b478f211a815f2707597c6032a98a573fbdee4a3109", 10: "c45a435f3c401eeb6d3a08b2f93669ee33e4ad2640e4e9a9a34937006ae8b308",
+    11: "acb33246c69545225a61fb60b44868e8bc8d25533c663aacabe449686bbed40c", 12: "7f7eba68d7be6b7076c17b6dc473a6d1770bcf1cb4266e7fb1e4642658050609",
+    13: "a84d1ceceb0ebc710ba2bc5ae60bb6c38abad15f650bf7e87cb901533125110d", 14: "157cdbdece96312986c9f44e03c232d4ca9aad55e4e259828f1ac451a93dd40a",
+    15: "a32f318c922b6404d6dd8eb2f65a73b05a49f14cb0b13f4828a840079e60460d"}.items()}
+
+
+@pytest.mark.parametrize("pattern,wit,inst", [
+    ("(((W W) (W W)) ((W W) (W W)))", [8, 9, 10, 11, 12, 13, 14, 15], []),          # merkle_tree_gadget.rs:218-258
+    ("(((W W) (I W)) ((I W) (W I)))", [8, 9, 11, 13, 14], [10, 12, 15]),            # :260-304
+    ("(((W W) (W W)) (W W))", [8, 9, 10, 11, 6, 7], []),                            # :306-345
+    ("(((W W) (W W)) W)", [8, 9, 10, 11, 3], []),                                   # :347-385
+    ("((W W) ((W W) (W W)))", [4, 5, 12, 13, 14, 15], []),                          # :387-427
+    ("(W ((W W) (W W)))", [2, 12, 13, 14, 15], []),                                 # :429-468
+])
+def test_merkle_tree_gadget_reference_cases(ctx, pattern, wit, inst):
+    root = bpg.be_to_scalar(W[1])
+    t = LabeledTranscript(b"MerkleTree")
+    p = bpg.Prover(ctx, t)
+    ivals = [bpg.be_to_scalar(W[i]) for i in inst]
+    _, wc, wv = bpg.commit_all_single(p, [W[i] for i in wit], [rs(b"mk", i) for i in range(len(wit))])
+    bpg.MerkleTree256(root, ivals, bpg.vars_to_lc(wv), pattern).prove(p, [], [])
+
+    def replay(v):
+        bpg.MerkleTree256(root, ivals, bpg.vars_to_lc(bpg.verifier_commit(v, wc)), pattern).verify(v, [], [])
+    check_against_oracle(ctx, p, t, wc, 16384, replay)
+
+
+def test_combine_gadgets(ctx):
+    # reference tests/combine_gadgets.rs:22-107: bounds + hash + merkle in one proof, 8192 generators
+    t = LabeledTranscript(b"CombinedGadgets")
+    p = bpg.Prover(ctx, t)
+    w1_scalar, w1_com, w1_var = bpg.commit(p, bytes([67]), [rs(b"cg", 0)])
+    image = H("0cfb0c17618211c607febf703ac3f3078f7d96798fae9d4a1682bc592f7cb126")
+    _, w2_com, w2_var = bpg.commit_single(p, image, rs(b"cg", 1))
+    lo, hi = bytes([17]), bytes([100])
+    bounds = bpg.BoundsCheck(lo, hi)
+    bdc, bdw = bounds.setup(p, w1_scalar, [rs(b"cg", 2), rs(b"cg", 3)])
+    bounds.prove(p, w1_var, bdw)
+    hsh = bpg.MimcHash256(w2_var)
+    hdc, hdw = hsh.setup(p, w1_scalar, [rs(b"cg", 4), rs(b"cg", 5)])
+    hsh.prove(p, w1_var, hdw)
+    root = bpg.be_to_scalar(H("0c8c87b648e8fa0d9726ee8225be0628794f2e1d1ab932421d45851a35d81ac1"))
+    leaf = bpg.be_to_scalar(W[3])
+    bpg.MerkleTree256(root, [leaf], [w2_var], "(W I)").prove(p, [], [])
+
+    def replay(v):
+        wv = bpg.verifier_commit(v, w1_com + [w2_com])
+        bpg.BoundsCheck(lo, hi).verify(v, [wv[0]], bpg.verifier_commit(v, bdc))
+        bpg.MimcHash256(wv[1]).verify(v, [wv[0]], bpg.verifier_commit(v, hdc))
+        bpg.MerkleTree256(root, [leaf], [wv[1]], "(W I)").verify(v, [], [])
+    check_against_oracle(ctx, p, t, w1_com + [w2_com] + bdc + hdc, 8192, replay)

@@ -1,0 +1,155 @@
+"""CPU tests of the product's host side (C++ inside libbpg_hip.so, no GPU needed): C-ABI exports, host scalar
+arithmetic, Merlin, MiMC, conversions and gadget assembly.  Circuits assembled by the product are handed to the
+ORACLE (tests/oracle_lib.py) for satisfaction / prove / verify checks."""
+import hashlib
+import re
+import pytest
+import bulletproofs_gadgets_amd as bpg
+import oracle_lib as O
+import pyref as R
+
+H = bytes.fromhex
+sc = lambda x: (x % R.L).to_bytes(32, "little")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = (O.ROOT / "include" / "bpg.h").read_text()
+    names = set(re.findall(r"\b(bpg_[a-z0-9_]+)\s*\(", hdr)) - {"bpg_status"}
+    assert len(names) > 40
+    lib = bpg.lib()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_fails_loudly():
+    # on the GPU box this creates a context; without a GPU it must raise DEVICE_ERROR (no CPU fallback)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(bpg.BpgError) as e:
+        bpg.Context(0)
+    assert e.value.status == 7
+    t = bpg.Transcript(b"x")
+    p = bpg.Prover(None, t)
+    with pytest.raises(bpg.BpgError) as e:
+        p.commit(sc(1), sc(2))
+    assert e.value.status == 7
+
+
+def test_host_scalar_semantics():
+    vals = [0, 1, R.L - 1, R.L, R.L + 5, 2**255 - 1, 2**256 - 1] + [int.from_bytes(hashlib.sha256(b"%d" % i).digest(), "little") for i in range(40)]
+    for i, a in enumerate(vals):
+        b = vals[(3 * i + 1) % len(vals)]
+        A, B = a.to_bytes(32, "little"), b.to_bytes(32, "little")
+        assert bpg.scalar_op("add", A, B) == sc(a + b)
+        assert bpg.scalar_op("sub", A, B) == sc(a - b)
+        assert bpg.scalar_op("mul", A, B) == sc(a * b)
+        assert bpg.scalar_op("reduce", A) == sc(a)
+        if a % R.L:
+            assert bpg.scalar_op("invert", A) == sc(pow(a % R.L, R.L - 2, R.L))
+    for i in range(20):
+        w = hashlib.sha512(b"w%d" % i).digest() if i else b"\xff" * 64
+        assert bpg.scalar_op("from_wide", w) == O.sc_wide(w)
+
+
+def test_host_merlin_matches_published_vector_and_oracle():
+    t = bpg.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    tp, to = bpg.Transcript(b"long"), O.Transcript(b"long")
+    for k in range(5):
+        msg = bytes(range(256)) * (k + 1)
+        tp.append_message(b"blob", msg); to.append(b"blob", msg)
+        assert tp.challenge_bytes(b"c", 100 + 90 * k) == to.challenge(b"c", 100 + 90 * k)
+        assert tp.state == to.state
+
+
+def test_conversions_reference_unit_tests():
+    # reference src/conversions.rs:100-150
+    B1 = H("7b2460be180544cd18e3e7e27330cec9517a314acbd4a011d273a59b480c1e00")
+    B2 = H("7b987cf97a9f1bd5492347d6f4e550ae2949a513de92fe5065350ebcd51db604")
+    assert bpg.be_to_scalar(B1) == bytes(reversed(B1))
+    s = bpg.be_to_scalars(B1 + B2)
+    assert s[0] == bytes(reversed(B2)) and s[1] == bytes(reversed(B1))
+    assert bpg.scalar_to_be(bpg.be_to_scalar(B1)) == B1
+    # from_bits: bit 255 cleared, no reduction
+    assert bpg.be_to_scalars(b"\xff" * 32)[0] == b"\xff" * 31 + b"\x7f"
+    assert len(bpg.be_to_scalars(b"\x01" * 33)) == 2
+
+
+def test_mimc_hash_kats(golden):
+    m = golden["mimc"]
+    be = lambda b: bytes(reversed(b)).hex()
+    assert be(bpg.mimc_hash(H(m["kat1_in"]))) == m["kat1_be"]
+    assert be(bpg.mimc_hash(H(m["kat2_in"]))) == m["kat2_be"]
+    assert be(bpg.mimc_hash(H(m["kat3_in"]))) == m["kat3_be"]
+    assert be(bpg.mimc_hash(b"John")) == m["john_be"]
+    for pre in [bytes([0xc4]) + bytes(range(31)), bytes([0x80]) + bytes(31), b"\xff" * 64, b"\x00" * 5 + b"\x01", b"a" * 2130]:
+        assert bpg.mimc_hash(pre) == O.mimc_hash(pre)
+
+
+def to_oracle(inst):
+    return O.FlatCircuit(inst.n, inst.m, inst.aL or None, inst.aR or None, inst.aO or None, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+
+
+def test_range_proof_assembly_and_oracle_roundtrip():
+    # reference src/utils.rs:46-90 (test_range_proof_1 ok with n = 56, test_range_proof_2 must fail with n = 48)
+    x = bpg.be_to_scalar(H("0522a64d7b931e"))
+    for nbits, ok in ((56, True), (48, False)):
+        tp = bpg.Transcript(b"RangeProof")
+        p = bpg.Prover(None, tp)
+        bpg.range_proof(p, x, nbits, x)
+        assert p.get_num_multiplications() == nbits and p.num_constraints() == 2 * nbits + 1
+        pi = p.instance()
+        assert O.satisfied(to_oracle(pi), b"") == ok
+        tv = bpg.Transcript(b"RangeProof")
+        v = bpg.Verifier(tv)
+        bpg.range_proof(v, x, nbits)
+        vi = v.instance()
+        assert (vi.n, vi.q) == (nbits, 2 * nbits + 1)
+        assert bytes(vi.term_var) == bytes(pi.term_var) and bytes(vi.row_ptr) == bytes(pi.row_ptr)
+        gens = O.Gens(64)
+        rc, proof, _ = O.prove(gens, tp.state, to_oracle(pi), b"", bytes(32), O.FLAG_FAST_MSM)
+        assert rc == 0
+        assert (O.verify(gens, tv.state, to_oracle(vi), b"", proof) == 0) == ok
+
+
+def test_merkle_assembly_sizes_and_witness_synthesis(golden):
+    # all-instance tree: no commitments needed, so the prover-side synthesis runs without a GPU
+    m = golden["mimc"]
+    leaf = bpg.be_to_scalar(H(m["leaf512_be"]))
+    root4 = bpg.be_to_scalar(H(m["levels512_be"][1]))        # 4 equal leaves -> level-2 digest (merkle_tree_gadget.rs:479-483)
+    tp = bpg.Transcript(b"MerkleTree")
+    p = bpg.Prover(None, tp)
+    g = bpg.MerkleTree256(root4, [leaf] * 4, [], "((I I) (I I))")
+    g.prove(p, [], [])
+    assert p.get_num_multiplications() == 3 * 1944 and p.num_constraints() == 3 * 3888 + 1
+    inst = p.instance()
+    assert O.satisfied(to_oracle(inst), b"")
+    # wrong root -> unsatisfied
+    p2 = bpg.Prover(None, bpg.Transcript(b"MerkleTree"))
+    bpg.MerkleTree256(leaf, [leaf] * 4, [], "((I I) (I I))").prove(p2, [], [])
+    assert not O.satisfied(to_oracle(p2.instance()), b"")
+    # pattern errors surface as INVALID_ARGUMENT, like the reference's assert
+    with pytest.raises(bpg.BpgError):
+        bpg.MerkleTree256(root4, [leaf] * 3, [], "((I I) (I I))").prove(bpg.Prover(None, bpg.Transcript(b"x")), [], [])
+    with pytest.raises(bpg.BpgError):
+        bpg.MerkleTree256(root4, [], [], "((I I) (I")
+
+
+def test_verifier_side_gadget_sizes():
+    # BoundsCheck over 8-byte bounds: 2*64 multipliers, 1 + 2*(2*64+1) constraints (SURVEY.md section 8 cfg 2)
+    tv = bpg.Transcript(b"BoundsCheck")
+    v = bpg.Verifier(tv)
+    w = v.commit(bytes(32))
+    d = [v.commit(bytes(32)), v.commit(bytes(32))]
+    bpg.BoundsCheck(bytes(8), b"\xff" * 8).verify(v, [w], d)
+    i = v.instance()
+    assert (i.n, i.q, i.m) == (128, 259, 3)
+    # MimcHash256 over one block, happy padding case: 972 multipliers, 1946 constraints (src/or/or_conjunction.rs:85)
+    v = bpg.Verifier(bpg.Transcript(b"MiMCHash"))
+    image, pre = v.commit(bytes(32)), v.commit(bytes(32))
+    d = [v.commit(bytes(32)), v.commit(bytes(32))]
+    bpg.MimcHash256(image).verify(v, [pre], d)
+    i = v.instance()
+    assert (i.n, i.q, i.m) == (972, 1946, 4)
