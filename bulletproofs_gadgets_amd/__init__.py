@@ -219,6 +219,20 @@ class Context:
         _chk(lib().bpg_msm_gens(self._h, C.c_uint64(first), C.c_uint64(len(s)), b"".join(s), b"".join(t), out))
         return out.raw
 
+    def profile_set(self, mode):
+        _chk(lib().bpg_profile_set(self._h, C.c_int32(mode)))
+
+    def profile_report(self):
+        import json
+        out = _buf(1 << 16)
+        _chk(lib().bpg_profile_report(self._h, out, C.c_uint64(1 << 16)))
+        return json.loads(out.value.decode())
+
+    def bench_fe_mul(self, iters=2000):
+        r = C.c_double()
+        _chk(lib().bpg_bench_fe_mul(self._h, C.c_uint32(iters), C.byref(r)))
+        return r.value
+
     # ---- PART 1 boundary on flattened instances
     def upload(self, inst: "FlatInstance"):
         h = C.c_void_p()

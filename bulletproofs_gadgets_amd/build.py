@@ -29,6 +29,7 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+           "-Xarch_host", "-march=x86-64-v3",     # host side only: BMI2 rotates / ANDN for the Keccak chain
            "-o", str(LIB)] + [str(s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

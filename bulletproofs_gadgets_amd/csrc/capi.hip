@@ -144,6 +144,12 @@ bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint
     return guard([&] { REQUIRE(ctx && out && (count == 0 || (s && t))); ctx->engine->msm_gens(first, count, s, t, out); });
 }
 
+bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode) { return guard([&] { REQUIRE(ctx && mode >= 0 && mode <= 2); ctx->engine->profile_set(mode); }); }
+bpg_status bpg_profile_report(bpg_ctx *ctx, char *out, uint64_t cap) {
+    return guard([&] { REQUIRE(ctx && out && cap); std::string r = ctx->engine->profile_report(); if (r.size() + 1 > cap) throw std::invalid_argument("profile_report: buffer too small"); std::memcpy(out, r.c_str(), r.size() + 1); });
+}
+bpg_status bpg_bench_fe_mul(bpg_ctx *ctx, uint32_t iters, double *out) { return guard([&] { REQUIRE(ctx && out && iters); *out = ctx->engine->bench_fe_mul(iters); }); }
+
 uint64_t bpg_proof_size(uint64_t n, uint32_t flags) {
     uint64_t N = 1, lg = 0; while (N < n) { N <<= 1; lg++; }
     return ((flags & BPG_FLAG_COMPACT_1PHASE) ? 1 + 11 * 32 : 14 * 32) + (2 * lg + 2) * 32;

@@ -14,6 +14,10 @@ namespace bpg {
 
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw DeviceError(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
 
+// launch on the engine stream, bracketed by HIP events when the profile asks for this kernel
+#define BPG_LAUNCH_ID(I, id, kernel, grid, block, ...) do { (I).prof_begin(id); hipLaunchKernelGGL(kernel, grid, block, 0, (I).st, __VA_ARGS__); (I).prof_end(id); } while (0)
+#define BPG_LAUNCH(I, kernel, grid, block, ...) BPG_LAUNCH_ID(I, KID_##kernel, kernel, grid, block, __VA_ARGS__)
+
 namespace {
 
 struct DevBuf {
@@ -76,11 +80,48 @@ struct DeviceCircuit {
     DevBuf aL, aR, aO, col_ptr, ent_row, ent_coef, coef;
 };
 
+// kernel ids for the optional HIP-event profile (bpg_profile_*)
+#define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
+    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_digits_count) X(k_msm_digits_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_msm_final) X(k_bench_fe_mul)
+enum KernelId {
+#define X(n) KID_##n,
+    BPG_KERNELS(X)
+#undef X
+    KID_COUNT
+};
+static const char *const kKernelNames[KID_COUNT] = {
+#define X(n) #n,
+    BPG_KERNELS(X)
+#undef X
+};
+
 struct Engine::Impl {
     hipStream_t st = nullptr;
+    // profiling: mode 0 off, 1 = k_fold_points only (cheap enough for timed regions), 2 = every kernel
+    int prof_mode = 0;
+    struct ProfRec { int id; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_open;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[KID_COUNT] = {0};
+    uint64_t prof_count[KID_COUNT] = {0};
+    double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && id == KID_k_fold_points); }
+    hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
+    void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
+    void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
+    void prof_note(int id, double alg_bytes, double act_bytes, double fm) { if (!prof_on(id)) return; prof_alg_bytes[id] += alg_bytes; prof_act_bytes[id] += act_bytes; prof_fm[id] += fm; }
+    void prof_collect() {
+        if (prof_open.empty()) return;
+        HIPCHK(hipStreamSynchronize(st));
+        for (ProfRec &r : prof_open) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, r.a, r.b)); prof_ms[r.id] += ms; prof_count[r.id]++; prof_pool.push_back(r.a); prof_pool.push_back(r.b); }
+        prof_open.clear();
+    }
+    void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots;
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf;
@@ -117,11 +158,45 @@ Engine::~Engine() {
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf};
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release();
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
+}
+
+void Engine::profile_set(int mode) { HIPCHK(hipSetDevice(device_)); impl_->prof_reset(); impl_->prof_mode = mode; }
+std::string Engine::profile_report() {
+    HIPCHK(hipSetDevice(device_));
+    impl_->prof_collect();
+    std::string out = "{";
+    bool first = true;
+    for (int i = 0; i < KID_COUNT; i++) {
+        if (!impl_->prof_count[i]) continue;
+        char buf[512];
+        std::snprintf(buf, sizeof buf, "%s\"%s\": {\"count\": %llu, \"total_ms\": %.6f, \"alg_bytes\": %.0f, \"device_bytes\": %.0f, \"field_mults\": %.0f}",
+                      first ? "" : ", ", kKernelNames[i], (unsigned long long)impl_->prof_count[i], impl_->prof_ms[i], impl_->prof_alg_bytes[i],
+                      impl_->prof_act_bytes[i], impl_->prof_fm[i]);
+        out += buf; first = false;
+    }
+    return out + "}";
+}
+// throughput of dependent-free field multiplications (the binding roofline of this path): returns multiplications / second
+double Engine::bench_fe_mul(uint32_t iters) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    const uint32_t blocks = 256 * 16, threads = 256;
+    I.small_sc.ensure((size_t)blocks * threads * sizeof(fe));
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(k_bench_fe_mul, dim3(blocks), dim3(threads), 0, I.st, I.small_sc.as<fe>(), 8u);     // warm-up
+    HIPCHK(hipEventRecord(a, I.st));
+    hipLaunchKernelGGL(k_bench_fe_mul, dim3(blocks), dim3(threads), 0, I.st, I.small_sc.as<fe>(), iters);
+    HIPCHK(hipEventRecord(b, I.st));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return (double)blocks * threads * iters * 4.0 / (ms * 1e-3);
 }
 
 void Engine::synchronize() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(impl_->st)); }
@@ -149,8 +224,8 @@ void Engine::gens_ensure(uint64_t capacity) {
     DevBuf fresh; fresh.ensure(2 * cap * sizeof(ge_niels));
     HIPCHK(hipMemcpyAsync(I.raw_rng.p, I.h_raw.p, 2 * cap * 64, hipMemcpyHostToDevice, I.st));
     const uint32_t cnt = (uint32_t)(2 * cap);
-    hipLaunchKernelGGL(k_gens_derive, dim3(cdiv(cnt, 256)), dim3(256), 0, I.st, I.raw_rng.as<uint32_t>(), I.scratch_ext.as<ge_ext>(), cnt);
-    hipLaunchKernelGGL(k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), 0, I.st, I.scratch_ext.as<ge_ext>(), fresh.as<ge_niels>(), cnt);
+    BPG_LAUNCH(I, k_gens_derive, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>(), I.scratch_ext.as<ge_ext>(), cnt);
+    BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), fresh.as<ge_niels>(), cnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(I.st));
     I.gens.release();
@@ -166,7 +241,7 @@ void Engine::gens_export(uint64_t first, uint64_t count, uint8_t *G_out, uint8_t
     I.comp.ensure(count * 32);
     for (int which = 0; which < 2; which++) {
         const ge_niels *src = I.gens.as<ge_niels>() + (which ? gens_cap_ : 0) + first;
-        hipLaunchKernelGGL(k_compress_niels, dim3(cdiv(count, 64)), dim3(64), 0, I.st, src, I.comp.as<uint8_t>(), (uint32_t)count);
+        BPG_LAUNCH(I, k_compress_niels, dim3(cdiv(count, 64)), dim3(64), src, I.comp.as<uint8_t>(), (uint32_t)count);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(which ? H_out : G_out, I.comp.p, count * 32, hipMemcpyDeviceToHost, I.st));
         HIPCHK(hipStreamSynchronize(I.st));
@@ -177,7 +252,7 @@ void Engine::pedersen_bases(uint8_t B[32], uint8_t Bb[32]) {
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
     I.comp.ensure(64);
-    hipLaunchKernelGGL(k_compress_niels, dim3(1), dim3(64), 0, I.st, I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), 2u);
+    BPG_LAUNCH(I, k_compress_niels, dim3(1), dim3(64), I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), 2u);
     HIPCHK(hipGetLastError());
     uint8_t out[64];
     HIPCHK(hipMemcpyAsync(out, I.comp.p, 64, hipMemcpyDeviceToHost, I.st));
@@ -198,7 +273,7 @@ void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, u
     I.small_sc.ensure(2 * k * 32); I.comp.ensure(k * 32);
     HIPCHK(hipMemcpyAsync(I.small_sc.p, hv.data(), k * 32, hipMemcpyHostToDevice, I.st));
     HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + k * 32, hr.data(), k * 32, hipMemcpyHostToDevice, I.st));
-    hipLaunchKernelGGL(k_pedersen, dim3(cdiv(k, 64)), dim3(64), 0, I.st, I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + k * 8,
+    BPG_LAUNCH(I, k_pedersen, dim3(cdiv(k, 64)), dim3(64), I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + k * 8,
                        I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), (uint32_t)k);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, I.comp.p, k * 32, hipMemcpyDeviceToHost, I.st));
@@ -210,7 +285,8 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     const uint32_t total = S.start[S.nseg];
     uint32_t per = total / (nmsm ? nmsm : 1); if (per < 1) per = 1;
     int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > 16) cc = 16;
-    const uint32_t c = (uint32_t)cc, W = (254 + c - 1) / c, nb = 1u << (c - 1);
+    // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
+    const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
     const uint32_t nkeys = nmsm * W * nb;
     const uint32_t seg = nb < 32 ? nb : 32, nsegpw = nb / seg;
     const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
@@ -220,15 +296,25 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
     HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)(nkeys + 1) * 4, st));
-    if (total) hipLaunchKernelGGL(k_msm_digits<0>, dim3(cdiv(total, 256)), dim3(256), 0, st, S, total, c, W, nb, counts.as<uint32_t>(), (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_scan_blocksums, dim3(nblocks), dim3(256), 0, st, counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, st, blocksum.as<uint32_t>(), nblocks);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nblocks), dim3(256), 0, st, counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-    if (total) hipLaunchKernelGGL(k_msm_digits<1>, dim3(cdiv(total, 256)), dim3(256), 0, st, S, total, c, W, nb, cursor.as<uint32_t>(), entries.as<uint32_t>());
-    hipLaunchKernelGGL(k_bucket_acc, dim3(cdiv(nkeys, 256)), dim3(256), 0, st, S, starts.as<uint32_t>(), entries.as<uint32_t>(), buckets.as<ge_ext>(), nkeys);
+    if (total) BPG_LAUNCH_ID((*this), KID_k_msm_digits_count, k_msm_digits<0>, dim3(cdiv(total, 256)), dim3(256), S, total, W, nb, counts.as<uint32_t>(), (uint32_t *)nullptr);
+    BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
+    BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
+    BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
+    if (total) BPG_LAUNCH_ID((*this), KID_k_msm_digits_scatter, k_msm_digits<1>, dim3(cdiv(total, 256)), dim3(256), S, total, W, nb, cursor.as<uint32_t>(), entries.as<uint32_t>());
+    {   // balanced sweep: chunk size 2^lgCH entries per thread, between 32 and 256 depending on the list length
+        const uint64_t M = (uint64_t)total * W;                 // upper bound of the entry count (zero digits are skipped)
+        uint32_t lgCH = 5; while (lgCH < 8 && (M >> lgCH) > 131072) lgCH++;
+        const uint32_t nchunks = cdiv(M ? M : 1, 1u << lgCH);
+        slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
+        ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
+        // the true entry count is starts[nkeys] (device side); threads past it exit immediately
+        BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(), buckets.as<ge_ext>(),
+                   slotA, slotB, nkeys, lgCH);
+        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH);
+    }
     const uint32_t nred = nmsm * W * nsegpw;
-    hipLaunchKernelGGL(k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), 0, st, buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
-    hipLaunchKernelGGL(k_msm_final, dim3(nmsm), dim3(256), 0, st, partial.as<ge_ext>(), d_result, W, nsegpw, c);
+    BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
+    BPG_LAUNCH((*this), k_msm_final, dim3(nmsm), dim3(256), partial.as<ge_ext>(), d_result, W, nsegpw);
     HIPCHK(hipGetLastError());
 }
 
@@ -252,13 +338,13 @@ void Engine::msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const ui
     if (count) {
         HIPCHK(hipMemcpyAsync(I.small_sc.p, s, count * 32, hipMemcpyHostToDevice, I.st));
         HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + count * 32, t, count * 32, hipMemcpyHostToDevice, I.st));
-        hipLaunchKernelGGL(k_sc_from_bytes, dim3(cdiv(2 * count, 256)), dim3(256), 0, I.st, I.small_sc.as<uint32_t>(), I.sLR.as<scm>(), (uint32_t)(2 * count));
+        BPG_LAUNCH(I, k_sc_from_bytes, dim3(cdiv(2 * count, 256)), dim3(256), I.small_sc.as<uint32_t>(), I.sLR.as<scm>(), (uint32_t)(2 * count));
     }
     MsmSegs S = seg_new();
     seg_push(S, I.sLR.as<scm>(), I.gens.as<ge_niels>() + first, (uint32_t)count, 0);
     seg_push(S, I.sLR.as<scm>() + count, I.gens.as<ge_niels>() + gens_cap_ + first, (uint32_t)count, 0);
     I.msm(S, 1, I.msm_result.as<ge_ext>());
-    hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, I.st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
+    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, I.comp.p, 32, hipMemcpyDeviceToHost, I.st));
     HIPCHK(hipStreamSynchronize(I.st));
@@ -309,7 +395,7 @@ DeviceCircuit *Engine::upload(const FlatCircuit &c) {
         for (int k = 0; k < 4; k++) {
             if (!cnts[k]) continue;
             HIPCHK(hipMemcpyAsync(I.small_sc.p, src[k]->data(), cnts[k] * 32, hipMemcpyHostToDevice, I.st));
-            hipLaunchKernelGGL(k_sc_from_bytes, dim3(cdiv(cnts[k], 256)), dim3(256), 0, I.st, I.small_sc.as<uint32_t>(), dst[k]->as<scm>(), (uint32_t)cnts[k]);
+            BPG_LAUNCH(I, k_sc_from_bytes, dim3(cdiv(cnts[k], 256)), dim3(256), I.small_sc.as<uint32_t>(), dst[k]->as<scm>(), (uint32_t)cnts[k]);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(I.st));
         }
@@ -384,7 +470,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     scm *sL = I.sLR.as<scm>(), *sR = sL + n;
     if (n) {
         HIPCHK(hipMemcpyAsync(I.raw_rng.p, I.h_raw.p, 2 * n * 64, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, I.raw_rng.as<uint32_t>(), sL, (uint32_t)(2 * n));
+        BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), I.raw_rng.as<uint32_t>(), sL, (uint32_t)(2 * n));
     }
     lap(tm ? &tm->msm_aiao : nullptr);
     {
@@ -394,7 +480,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 0);
         I.msm(S, 1, I.msm_result.as<ge_ext>() + 2);
     }
-    hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
+    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
     HIPCHK(hipGetLastError());
     uint8_t pts[96];
     HIPCHK(hipMemcpyAsync(pts, I.comp.p, 96, hipMemcpyDeviceToHost, st));
@@ -419,20 +505,20 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.wAll.ensure((c->ncols ? c->ncols : 1) * sizeof(scm));
     auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
         uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
-        hipLaunchKernelGGL(k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), 0, st, to_scm(base), out, (uint32_t)count, lgT);
+        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
     };
     exp_table(y, I.ypow.as<scm>(), N);
     exp_table(yinv, I.yinvpow.as<scm>(), N);
     exp_table(z, I.zpow.as<scm>(), q + 1);
     if (c->ncols)
-        hipLaunchKernelGGL(k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), 0, st, c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
+        BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
                            c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)c->ncols, (uint32_t)(3 * n));
     scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;
     const uint32_t pblocks = n ? std::min<uint32_t>(cdiv(n, 256), 1024) : 1;
     I.red_partial.ensure((size_t)pblocks * 6 * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
-    hipLaunchKernelGGL(k_poly_t, dim3(pblocks), dim3(256), 0, st, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
+    BPG_LAUNCH(I, k_poly_t, dim3(pblocks), dim3(256), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
                        I.ypow.as<scm>(), I.yinvpow.as<scm>(), I.red_partial.as<scm>(), (uint32_t)n);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(6), dim3(256), 0, st, I.red_partial.as<scm>(), pblocks, 6u, I.red_out.as<scm>());
+    BPG_LAUNCH(I, k_reduce_partials, dim3(6), dim3(256), I.red_partial.as<scm>(), pblocks, 6u, I.red_out.as<scm>());
     HIPCHK(hipGetLastError());
     scm h_t[6]; std::vector<scm> h_wV(m ? m : 1);
     HIPCHK(hipMemcpyAsync(h_t, I.red_out.p, 6 * sizeof(scm), hipMemcpyDeviceToHost, st));
@@ -460,7 +546,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const Scalar w = T.challenge_scalar("w");
 
     I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm));
-    hipLaunchKernelGGL(k_poly_eval, dim3(cdiv(N, 256)), dim3(256), 0, st, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
+    BPG_LAUNCH(I, k_poly_eval, dim3(cdiv(N, 256)), dim3(256), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
                        I.ypow.as<scm>(), I.yinvpow.as<scm>(), to_scm(x), I.lv.as<scm>(), I.rv.as<scm>(), (uint32_t)n, (uint32_t)N);
     HIPCHK(hipGetLastError());
     lap(tm ? &tm->poly : nullptr);
@@ -487,10 +573,10 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + h, *sRG = sLH + h, *sRH = sRG + h;
         const uint32_t blocks = std::min<uint32_t>(cdiv(h, 256), 1024);
         I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
-        hipLaunchKernelGGL(k_ipa_prep, dim3(blocks), dim3(256), 0, st, a, b, I.yinvpow.as<scm>(), to_scm(Gamma), to_scm(Eta), uch_m,
+        BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), to_scm(Gamma), to_scm(Eta), uch_m,
                            (uint32_t)first, (uint32_t)n, (uint32_t)h, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
-        hipLaunchKernelGGL(k_reduce_partials, dim3(2), dim3(256), 0, st, I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
-        hipLaunchKernelGGL(k_scale2, dim3(1), dim3(64), 0, st, I.extras.as<scm>() + 3, w_m);
+        BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
+        BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
         {
             MsmSegs S = seg_new();
             seg_push(S, sLG, Gst + h, (uint32_t)h, 0);
@@ -501,7 +587,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
             I.msm(S, 2, I.msm_result.as<ge_ext>());
         }
-        hipLaunchKernelGGL(k_compress, dim3(1), dim3(64), 0, st, I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
+        BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
         HIPCHK(hipGetLastError());
         uint8_t lr[64];
         HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
@@ -510,7 +596,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         T.append_point("L", lr); T.append_point("R", lr + 32);
         proof.insert(proof.end(), lr, lr + 64);
         const Scalar u = T.challenge_scalar("u"), uinv = u.invert();
-        hipLaunchKernelGGL(k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), 0, st, a, b, to_scm(u), to_scm(uinv), (uint32_t)h);
+        BPG_LAUNCH(I, k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), a, b, to_scm(u), to_scm(uinv), (uint32_t)h);
         if (h > 1 || true) {
             // generator fold: Gst'[i] = Gst[i] + sG * Gst[h+i],  Hst'[i] = Hst[i] + sH * Hst[h+i]
             const Scalar sGA = u * u, sHA = uinv * uinv * yinv_pow2[ceil_log2(h)];
@@ -522,8 +608,18 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             HIPCHK(hipMemcpyAsync(I.naf.p, hn, sizeof(FoldNaf), hipMemcpyHostToDevice, st));
             const uint32_t split = first ? (uint32_t)(n - h) : (uint32_t)h;
             ge_niels *dst = (round & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            hipLaunchKernelGGL(k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), 0, st, Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<FoldNaf>(), (uint32_t)h, split);
-            hipLaunchKernelGGL(k_normalize_niels, dim3(cdiv(cdiv(2 * h, NORM_K), 256)), dim3(256), 0, st, I.scratch_ext.as<ge_ext>(), dst, (uint32_t)(2 * h));
+            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<FoldNaf>(), (uint32_t)h, split);
+            {   // bookkeeping for the roofline: 4h points read + 2h written at 32 B (information content) resp. 96/128 B (device formats);
+                // field multiplications: 8 per doubling, 7 per mixed addition
+                double fm = 0;
+                for (int cls = 0; cls < 4; cls++) {
+                    int adds = 0; for (int k = 0; k <= hn->top[cls]; k++) adds += hn->d[cls][k] != 0;
+                    const double lanes = (cls & 1) ? (double)(h - split) : (double)split;
+                    fm += lanes * (8.0 * (hn->top[cls] + 1) + 7.0 * adds + 7.0);
+                }
+                I.prof_note(KID_k_fold_points, 32.0 * 6 * h, 96.0 * 4 * h + 128.0 * 2 * h, fm);
+            }
+            BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * h, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, (uint32_t)(2 * h));
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));      // hn (pinned) is rewritten next round
             Gst = dst; Hst = dst + h;

@@ -43,6 +43,10 @@ public:
     std::vector<uint8_t> prove(DeviceCircuit *c, Transcript &transcript, const std::vector<Scalar> &v_blinding,
                                const uint8_t rng_seed[32], uint32_t flags, ProveTimings *timings = nullptr);
     void synchronize();
+    // HIP-event profile on the engine's own stream: mode 0 off, 1 = dominant kernel (k_fold_points) only, 2 = all kernels
+    void profile_set(int mode);
+    std::string profile_report();          // JSON: {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}}
+    double bench_fe_mul(uint32_t iters);   // measured field-multiplication throughput (integer-VALU roofline)
     void *stream_handle() const { return stream_; }
     // names of the kernels launched by the last prove(), with counts (diagnostics for bench.py)
     struct Impl;

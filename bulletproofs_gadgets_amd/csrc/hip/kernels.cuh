@@ -108,6 +108,15 @@ __global__ void __launch_bounds__(64) k_pedersen(const uint32_t *__restrict__ v,
     ge_compress(out + 32 * (size_t)i, acc);
 }
 
+// integer-VALU roofline probe: 4 independent chains of field multiplications per thread, nothing but registers
+__global__ void __launch_bounds__(256) k_bench_fe_mul(fe *__restrict__ out, uint32_t iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = FE_D(), b = FE_SQRTM1(), c = FE_D2(), d = FE_ONE_MINUS_D_SQ();
+    a.v[0] ^= t; b.v[1] ^= t; c.v[2] ^= t; d.v[3] ^= t;
+    for (uint32_t i = 0; i < iters; i++) { a = fe_mul(a, b); b = fe_mul(b, c); c = fe_mul(c, d); d = fe_mul(d, a); }
+    out[t] = fe_add(fe_add(a, b), fe_add(c, d));
+}
+
 // ------------------------------------------------------------------------------------------------ scalar vectors
 __global__ void __launch_bounds__(256) k_sc_from_bytes(const uint32_t *__restrict__ in, scm *__restrict__ out, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -298,12 +307,15 @@ __global__ void __launch_bounds__(256) k_fold_points(const ge_niels *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ multiscalar multiplication
-// Signed c-bit digits of a canonical scalar (value < 2^253). digit w in (-2^(c-1), 2^(c-1)].
-__device__ __forceinline__ int32_t msm_digit(const uint32_t w[8], uint32_t c, uint32_t win, uint32_t &carry) {
-    uint32_t off = win * c, wi = off >> 5, sh = off & 31;
+// Window j of W covers bits [off(j), off(j+1)) with off(j) = j*254/W: near-equal widths, so that the top window keeps
+// (almost) a full width of entropy - with fixed c-bit windows the last one holds only 253 mod c bits and a handful of
+// buckets would receive every term.  Signed digits: digit j in (-2^(wd-1), 2^(wd-1)], wd = width of window j.
+__device__ __forceinline__ uint32_t msm_off(uint32_t j, uint32_t W) { return (j * 254u) / W; }
+__device__ __forceinline__ int32_t msm_digit(const uint32_t w[8], uint32_t W, uint32_t win, uint32_t &carry) {
+    uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
     uint64_t two = (uint64_t)(wi < 8 ? w[wi] : 0u) | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
-    uint32_t raw = (uint32_t)((two >> sh) & ((1u << c) - 1u)) + carry;
-    if (raw > (1u << (c - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << c); }
+    uint32_t raw = (uint32_t)((two >> sh) & ((1u << wd) - 1u)) + carry;
+    if (raw > (1u << (wd - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << wd); }
     carry = 0; return (int32_t)raw;
 }
 __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
@@ -316,7 +328,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // pass 0: histogram (counts[key]++), pass 1: scatter entries to cursor[key]++.
 // key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment
 template <int PASS>
-__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, uint32_t total, uint32_t c, uint32_t W, uint32_t nb,
+__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, uint32_t total, uint32_t W, uint32_t nb,
                                                     uint32_t *__restrict__ counts_or_cursor, uint32_t *__restrict__ entries) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -324,7 +336,7 @@ __global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, uint32_t total, u
     uint32_t w[8]; sc_to_words(w, S.sc[s][i]);
     uint32_t carry = 0, base = S.msm[s] * W;
     for (uint32_t win = 0; win < W; win++) {
-        int32_t d = msm_digit(w, c, win, carry);
+        int32_t d = msm_digit(w, W, win, carry);
         if (d == 0) continue;
         uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
         uint32_t key = (base + win) * nb + (mag - 1);
@@ -371,19 +383,51 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) starts[nkeys] = blocksum[gridDim.x];
 }
 
-// bucket sweep: one thread per bucket walks its entry list (gathering 96-byte Niels points) and stores the bucket sum
-__global__ void __launch_bounds__(256) k_bucket_acc(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
-                                                    ge_ext *__restrict__ buckets, uint32_t nkeys) {
-    uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key >= nkeys) return;
+// Balanced bucket sweep.  The entry list is sorted by bucket (starts[]); thread c adds the points of the fixed-size chunk
+// [c*CH, (c+1)*CH) whatever buckets it crosses, so a bucket that received thousands of terms (identical scalars: the -y^h
+// padding terms of the first IPA round, repeated witness values, range-proof bits) is spread over many threads instead of
+// serialising one.  A bucket that lies inside one chunk is stored directly; a bucket that crosses chunk boundaries leaves
+// one partial per chunk (slotA = piece at the chunk's beginning, slotB = piece at its end) for k_bucket_combine.
+__global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
+                                                       ge_ext *__restrict__ buckets, ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB,
+                                                       uint32_t nkeys, uint32_t lgCH) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e0 = c << lgCH;
+    const uint32_t M = starts[nkeys];                      // true entry count (zero digits were skipped)
+    if (e0 >= M) return;
+    const uint32_t e1 = (e0 + (1u << lgCH) < M) ? e0 + (1u << lgCH) : M;
+    uint32_t lo = 0, hi = nkeys + 1;                       // upper_bound(starts, e0) - 1 = bucket of entry e0
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e0) lo = mid + 1; else hi = mid; }
+    uint32_t k = lo - 1, kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
     ge_ext acc = ge_identity();
-    uint32_t e0 = starts[key], e1 = starts[key + 1];
     for (uint32_t e = e0; e < e1; e++) {
-        uint32_t ent = entries[e];
+        if (e >= kend) {
+            if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
+            else { if (seg_begin == e0) slotA[c] = acc; /* a piece ending inside the chunk cannot also end it */ }
+            acc = ge_identity(); seg_begin = e;
+            do { k++; kstart = kend; kend = starts[k + 1]; } while (e >= kend);
+        }
+        const uint32_t ent = entries[e];
         const ge_niels q = S.pts[(ent >> 27) & 7u][ent & 0x07ffffffu];
         acc = ge_madd_signed(acc, q, ent >> 31);
     }
-    buckets[key] = acc;
+    if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
+    else { if (seg_begin == e0) slotA[c] = acc; if (kend >= e1) slotB[c] = acc; }
+}
+
+// one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] otherwise
+__global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
+                                                        const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
+                                                        uint32_t nkeys, uint32_t lgCH) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkeys) return;
+    const uint32_t s0 = starts[k], s1 = starts[k + 1];
+    if (s0 == s1) { buckets[k] = ge_identity(); return; }
+    const uint32_t c0 = s0 >> lgCH, c1 = (s1 - 1) >> lgCH;
+    if (c0 == c1) return;
+    ge_ext acc = slotB[c0];
+    for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
+    buckets[k] = acc;
 }
 
 // per (msm, window, segment of SEG buckets): sum_b (b+1) * bucket[b] over the segment -> partial
@@ -398,13 +442,13 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
     // acc = sum (b - lo + 1) B_b ; add lo * run
     ge_ext m = ge_identity();
-    for (int32_t k = 31; k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }
+    for (int32_t k = 15; k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15
     partial[t] = ge_add(acc, m);
 }
 
 // one block per msm: window sums from the partials, Horner over windows, result in extended coordinates
 __global__ void __launch_bounds__(256) k_msm_final(const ge_ext *__restrict__ partial, ge_ext *__restrict__ result,
-                                                  uint32_t W, uint32_t nseg_per_win, uint32_t c) {
+                                                  uint32_t W, uint32_t nseg_per_win) {
     __shared__ ge_ext lds[256];
     const ge_ext *P = partial + (size_t)blockIdx.x * W * nseg_per_win;
     ge_ext total = ge_identity();
@@ -417,7 +461,7 @@ __global__ void __launch_bounds__(256) k_msm_final(const ge_ext *__restrict__ pa
             __syncthreads();
         }
         if (threadIdx.x == 0) {
-            if (win != (int32_t)W - 1) for (uint32_t k = 0; k < c; k++) total = ge_dbl(total);
+            if (win != (int32_t)W - 1) { const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W); for (uint32_t k = 0; k < shift; k++) total = ge_dbl(total); }
             total = ge_add(total, lds[0]);
         }
         __syncthreads();

@@ -92,9 +92,22 @@ public:
 private:
     uint8_t *bytes() { return reinterpret_cast<uint8_t *>(st_); }
     void run_f() { uint8_t *b = bytes(); b[pos_] ^= pos_begin_; b[pos_ + 1] ^= 0x04; b[R + 1] ^= 0x80; keccak_f1600_host(st_); pos_ = 0; pos_begin_ = 0; }
-    void absorb(const uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { b[pos_++] ^= d[i]; if (pos_ == R) run_f(); } }
-    void overwrite(const uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { b[pos_++] = d[i]; if (pos_ == R) run_f(); } }
-    void squeeze(uint8_t *d, size_t n) { uint8_t *b = bytes(); for (size_t i = 0; i < n; i++) { d[i] = b[pos_]; b[pos_++] = 0; if (pos_ == R) run_f(); } }
+    // fast paths: an operation that stays inside the current block touches the state with memcpy/memset-sized moves
+    void absorb(const uint8_t *d, size_t n) {
+        uint8_t *b = bytes();
+        if (pos_ + n < (size_t)R) { for (size_t i = 0; i < n; i++) b[pos_ + i] ^= d[i]; pos_ = (uint8_t)(pos_ + n); return; }
+        for (size_t i = 0; i < n; i++) { b[pos_++] ^= d[i]; if (pos_ == R) run_f(); }
+    }
+    void overwrite(const uint8_t *d, size_t n) {
+        uint8_t *b = bytes();
+        if (pos_ + n < (size_t)R) { std::memcpy(b + pos_, d, n); pos_ = (uint8_t)(pos_ + n); return; }
+        for (size_t i = 0; i < n; i++) { b[pos_++] = d[i]; if (pos_ == R) run_f(); }
+    }
+    void squeeze(uint8_t *d, size_t n) {
+        uint8_t *b = bytes();
+        if (pos_ + n < (size_t)R) { std::memcpy(d, b + pos_, n); std::memset(b + pos_, 0, n); pos_ = (uint8_t)(pos_ + n); return; }
+        for (size_t i = 0; i < n; i++) { d[i] = b[pos_]; b[pos_++] = 0; if (pos_ == R) run_f(); }
+    }
     void begin_op(uint8_t flags, bool more) {
         if (more) return;
         uint8_t old = pos_begin_;

@@ -90,6 +90,12 @@ bpg_status bpg_r1cs_prove(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t t
                           uint8_t *proof_out, uint64_t *proof_len);
 uint64_t bpg_proof_size(uint64_t n_multipliers, uint32_t flags);
 
+/* measurement hooks (bench.py): HIP events on the engine's own stream. mode 0 off, 1 = dominant kernel only, 2 = all kernels;
+ * report = JSON text {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}} accumulated since the last set. */
+bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);
+bpg_status bpg_profile_report(bpg_ctx *ctx, char *out, uint64_t cap);
+bpg_status bpg_bench_fe_mul(bpg_ctx *ctx, uint32_t iters, double *mults_per_second);
+
 /* test hook: compress(sum s_i*G[first+i] + t_i*H[first+i]) through the bucket-method MSM kernels */
 bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
 
