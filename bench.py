@@ -100,15 +100,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    gathered = None
-    if dist is not None:
-        gathered = [torch.empty(bpg.lib().bpg_proof_size(inst.n, 0), dtype=torch.uint8, device="cuda") for _ in range(world)]
+    from bulletproofs_gadgets_amd.batch import gather_proofs
+    proof_len = bpg.lib().bpg_proof_size(inst.n, 0)
 
     def step(i, timings=False):
         out = res.prove(state, inst.v_blinding, seed_for(i), 0, timings=timings)
-        if dist is not None:   # the only data that crosses xGMI: the finished proof bytes
-            mine = torch.frombuffer(bytearray(out[0]), dtype=torch.uint8).cuda()
-            dist.all_gather(gathered, mine)
+        if dist is not None:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
+            proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device="cuda")
+            assert len(proofs) == world
         return out
 
     for i in range(args.warmup):
