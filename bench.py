@@ -49,6 +49,48 @@ def cpu_baseline(ctx, bpg, workloads, leaves, seconds_hint=20.0):
             "seconds": dt}
 
 
+def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, steps):
+    """Secondary figure (never `value`): B independent proofs in flight on one GPU, one engine context + host thread each.
+    The serial TranscriptRng chain of one proof then overlaps the kernels of the others."""
+    import threading
+    ctxs, ress = [ctx0], [res0]
+    for _ in range(n_ctx - 1):
+        c = bpg.Context(device)
+        c.gens_ensure(capacity)
+        ctxs.append(c); ress.append(c.upload(inst))
+    start = threading.Barrier(n_ctx + 1)
+    errs = []
+
+    def worker(k):
+        try:
+            ress[k].prove(state, inst.v_blinding, bytes([k, 255]) + bytes(30), 0)       # warm-up (workspace allocation)
+            start.wait()
+            for i in range(steps):
+                ress[k].prove(state, inst.v_blinding, bytes([k, i]) + bytes(30), 0)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+            try:
+                start.abort()
+            except Exception:
+                pass
+    th = [threading.Thread(target=worker, args=(k,)) for k in range(n_ctx)]
+    for t in th:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for r in ress[1:]:
+        r.free()
+    for c in ctxs[1:]:
+        c.close()
+    if errs:
+        raise RuntimeError(errs[0])
+    return {"proofs_in_flight": n_ctx, "proofs": n_ctx * steps, "seconds": dt, "value": inst.q * n_ctx * steps / dt,
+            "unit": "constraints/s", "note": "independent proofs per GPU, one engine context and host thread each; not the headline"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,6 +100,7 @@ def main():
     ap.add_argument("--baseline-leaves", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-profile", action="store_true", help="one extra, untimed step with HIP events around every kernel")
+    ap.add_argument("--in-flight", type=int, default=4, help="secondary measurement: independent proofs in flight on ONE GPU (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +216,11 @@ def main():
                "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}}
         if kernels is not None:
             out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])}
+        if world == 1 and args.in_flight > 1:
+            try:
+                out["in_flight"] = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, local_rank, args.in_flight, max(2, args.steps))
+            except Exception as e:      # noqa: BLE001 - a failed secondary measurement must not lose the headline
+                out["in_flight"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves)
             out["cpu_baseline"]["host"] = "%d logical CPUs visible; 1 used" % (os.cpu_count() or 0)

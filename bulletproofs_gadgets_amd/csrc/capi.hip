@@ -1,6 +1,7 @@
 // extern "C" surface declared in include/bpg.h.  Translates C handles to the C++ host mirror (host/*.hpp) and the
 // HIP engine (engine.hip); every exception is mapped to a bpg_status and a thread-local message.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -358,6 +359,23 @@ bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint
         if (s.size() > *n_out) throw std::invalid_argument("be_to_scalars: output capacity too small");
         for (size_t i = 0; i < s.size(); i++) s[i].to_bytes(out + 32 * i);
         *n_out = s.size();
+    });
+}
+bpg_status bpg_keccak_selftest(uint64_t seed, uint32_t rounds, int32_t *impl_out, double *ns_out) {
+    return guard([&] {
+        uint64_t a[25], b[25];
+        for (int i = 0; i < 25; i++) a[i] = b[i] = seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i * 0xd1342543de82ef95ULL + (seed >> (i & 31));
+        for (uint32_t r = 0; r < rounds; r++) {
+            keccak_f1600_scalar(a); keccak_f1600_host(b);
+            if (std::memcmp(a, b, sizeof a) != 0) throw std::runtime_error("keccak: vector and scalar implementations disagree");
+            a[r % 25] ^= r; b[r % 25] ^= r;
+        }
+        if (impl_out) *impl_out = keccak_have_avx512() ? 1 : 0;
+        if (ns_out) {
+            auto t0 = std::chrono::steady_clock::now();
+            for (int r = 0; r < 200000; r++) keccak_f1600_host(b);
+            *ns_out = std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count() / 200000.0 + (b[0] == 1 ? 1e-9 : 0);
+        }
     });
 }
 bpg_status bpg_scalar_op(int32_t op, const uint8_t *a, const uint8_t *b, uint8_t out[32]) {

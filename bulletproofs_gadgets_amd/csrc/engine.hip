@@ -84,7 +84,7 @@ struct DeviceCircuit {
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_digits_count) X(k_msm_digits_scatter) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_msm_final) X(k_bench_fe_mul)
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_bench_fe_mul)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -121,7 +121,7 @@ struct Engine::Impl {
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums;
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf;
@@ -158,7 +158,7 @@ Engine::~Engine() {
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots};
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release();
     (void)hipStreamDestroy(impl_->st);
@@ -314,7 +314,9 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     }
     const uint32_t nred = nmsm * W * nsegpw;
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
-    BPG_LAUNCH((*this), k_msm_final, dim3(nmsm), dim3(256), partial.as<ge_ext>(), d_result, W, nsegpw);
+    wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
+    BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(256), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw);
+    BPG_LAUNCH((*this), k_msm_horner, dim3(nmsm), dim3(256), wsums.as<ge_ext>(), d_result, W);
     HIPCHK(hipGetLastError());
 }
 

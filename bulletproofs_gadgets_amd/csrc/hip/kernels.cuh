@@ -446,27 +446,77 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     partial[t] = ge_add(acc, m);
 }
 
-// one block per msm: window sums from the partials, Horner over windows, result in extended coordinates
-__global__ void __launch_bounds__(256) k_msm_final(const ge_ext *__restrict__ partial, ge_ext *__restrict__ result,
-                                                  uint32_t W, uint32_t nseg_per_win) {
+// window sums: one block per (msm, window) adds that window's segment partials (strided loads, LDS tree)
+__global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ partial, ge_ext *__restrict__ wsum, uint32_t nseg_per_win) {
     __shared__ ge_ext lds[256];
-    const ge_ext *P = partial + (size_t)blockIdx.x * W * nseg_per_win;
-    ge_ext total = ge_identity();
-    for (int32_t win = (int32_t)W - 1; win >= 0; win--) {
-        ge_ext acc = ge_identity();
-        for (uint32_t s = threadIdx.x; s < nseg_per_win; s += 256) acc = ge_add(acc, P[(size_t)win * nseg_per_win + s]);
-        lds[threadIdx.x] = acc; __syncthreads();
-        for (uint32_t d = 128; d > 0; d >>= 1) {
-            if (threadIdx.x < d && threadIdx.x + d < nseg_per_win) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            if (win != (int32_t)W - 1) { const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W); for (uint32_t k = 0; k < shift; k++) total = ge_dbl(total); }
-            total = ge_add(total, lds[0]);
-        }
+    const ge_ext *P = partial + (size_t)blockIdx.x * nseg_per_win;
+    ge_ext acc = ge_identity();
+    for (uint32_t s = threadIdx.x; s < nseg_per_win; s += 256) acc = ge_add(acc, P[s]);
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d && threadIdx.x + d < nseg_per_win) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) result[blockIdx.x] = total;
+    if (threadIdx.x == 0) wsum[blockIdx.x] = lds[0];
+}
+
+// Horner over the window sums, result = sum_j 2^off(j) * S_j: about 250 DEPENDENT doublings, the serial tail of every MSM.
+// One block of 4 waves per MSM; the four independent field products of each doubling / addition step are computed by the
+// four waves concurrently (each wave is on its own SIMD, its lanes all hold the same value) and exchanged through LDS.
+// A single lane needs ~2,600 instructions per doubling; here each wave issues ~1/4 of that between two barriers.
+struct HornerLds { fe c[4]; fe s[4]; };
+__device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv) {
+    // L.c = (X, Y, Z, T) -> doubled point in L.c
+    fe in = (wv == 3) ? fe_add(L.c[0], L.c[1]) : L.c[wv];          // X, Y, Z, X+Y
+    fe sq = fe_sq(in);
+    __syncthreads();
+    L.s[wv] = sq;                                                  // XX, YY, ZZ, (X+Y)^2
+    __syncthreads();
+    fe XX = L.s[0], YY = L.s[1];
+    fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    fe a, b;
+    if (wv == 1) { a = YpX; b = YmX; }                              // Y3 = YpX * YmX
+    else {
+        fe ZZ2 = fe_add(L.s[2], L.s[2]);
+        fe cT = fe_sub(ZZ2, YmX), cX = fe_sub(L.s[3], YpX);
+        if (wv == 0) { a = cX; b = cT; }                            // X3 = cX * cT
+        else if (wv == 2) { a = YmX; b = cT; }                      // Z3 = YmX * cT
+        else { a = cX; b = YpX; }                                   // T3 = cX * YpX
+    }
+    fe r = fe_mul(a, b);
+    L.c[wv] = r;
+    __syncthreads();
+}
+__device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32_t wv) {
+    // L.c += q   (extended + extended, unified formulas)
+    fe X1 = L.c[0], Y1 = L.c[1];
+    fe p;
+    if (wv == 0) p = fe_mul(fe_sub(Y1, X1), fe_sub(q.Y, q.X));      // A
+    else if (wv == 1) p = fe_mul(fe_add(Y1, X1), fe_add(q.Y, q.X)); // B
+    else if (wv == 2) p = fe_mul(fe_mul(L.c[3], q.T), FE_D2());     // C
+    else { p = fe_mul(L.c[2], q.Z); p = fe_add(p, p); }             // D
+    __syncthreads();
+    L.s[wv] = p;
+    __syncthreads();
+    fe A = L.s[0], B = L.s[1], C = L.s[2], D = L.s[3];
+    fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    fe r = (wv == 0) ? fe_mul(E, F) : (wv == 1) ? fe_mul(G, H) : (wv == 2) ? fe_mul(F, G) : fe_mul(E, H);
+    L.c[wv] = r;
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
+    __shared__ HornerLds L;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index, uniform
+    const ge_ext *S = wsum + (size_t)blockIdx.x * W;
+    if (threadIdx.x == 0) { ge_ext t = S[W - 1]; L.c[0] = t.X; L.c[1] = t.Y; L.c[2] = t.Z; L.c[3] = t.T; }
+    __syncthreads();
+    for (int32_t win = (int32_t)W - 2; win >= 0; win--) {
+        const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W);
+        for (uint32_t k = 0; k < shift; k++) horner_dbl(L, wv);
+        const ge_ext q = S[win];
+        horner_add(L, q, wv);
+    }
+    if (threadIdx.x == 0) { ge_ext t; t.X = L.c[0]; t.Y = L.c[1]; t.Z = L.c[2]; t.T = L.c[3]; result[blockIdx.x] = t; }
 }
 
 }  // namespace bpg

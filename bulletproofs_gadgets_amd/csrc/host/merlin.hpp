@@ -14,8 +14,8 @@ namespace bpg {
 
 static inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
-// Keccak-f[1600], fully unrolled round body on 25 lane variables.
-static inline void keccak_f1600_host(uint64_t s[25]) {
+// Keccak-f[1600], scalar: fully unrolled round body on 25 lane variables.
+static inline void keccak_f1600_scalar(uint64_t s[25]) {
     static const uint64_t RC[24] = {
         0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
         0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
@@ -47,6 +47,97 @@ static inline void keccak_f1600_host(uint64_t s[25]) {
     s[10] = a10; s[11] = a11; s[12] = a12; s[13] = a13; s[14] = a14; s[15] = a15; s[16] = a16; s[17] = a17; s[18] = a18; s[19] = a19;
     s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
 }
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+// Keccak-f[1600] with AVX-512F: one zmm per plane y (lanes x = 0..4 in elements 0..4).  theta and rho act inside planes,
+// pi is split in two: "pi1" permutes each plane so that element y' of register j holds B[x' = j][y'], which lets chi run
+// ACROSS registers and leaves the state transposed (register = x, element = y); "pi2" transposes back with
+// unpack / two-source permutes.  About 38 vector instructions per round against ~150 scalar ones; the TranscriptRng
+// chain of a 2^20-gate proof is two million dependent permutations, so this is the prover's serial floor.
+__attribute__((target("avx512f"))) static inline void keccak_f1600_avx512(uint64_t s[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    const __mmask8 m5 = 0x1f;
+    __m512i P0 = _mm512_maskz_loadu_epi64(m5, s), P1 = _mm512_maskz_loadu_epi64(m5, s + 5), P2 = _mm512_maskz_loadu_epi64(m5, s + 10),
+            P3 = _mm512_maskz_loadu_epi64(m5, s + 15), P4 = _mm512_maskz_loadu_epi64(m5, s + 20);
+    const __m512i prev = _mm512_setr_epi64(4, 0, 1, 2, 3, 5, 6, 7), next = _mm512_setr_epi64(1, 2, 3, 4, 0, 5, 6, 7);
+    // rho offsets r[x][y], one vector per plane y
+    const __m512i rho0 = _mm512_setr_epi64(0, 1, 62, 28, 27, 0, 0, 0), rho1 = _mm512_setr_epi64(36, 44, 6, 55, 20, 0, 0, 0),
+                  rho2 = _mm512_setr_epi64(3, 10, 43, 25, 39, 0, 0, 0), rho3 = _mm512_setr_epi64(41, 45, 15, 21, 8, 0, 0, 0),
+                  rho4 = _mm512_setr_epi64(18, 2, 61, 56, 14, 0, 0, 0);
+    // pi1: Q_j[y'] = P_j[(j + 3 y') mod 5]
+    const __m512i pi0 = _mm512_setr_epi64(0, 3, 1, 4, 2, 5, 6, 7), pi1 = _mm512_setr_epi64(1, 4, 2, 0, 3, 5, 6, 7),
+                  pi2 = _mm512_setr_epi64(2, 0, 3, 1, 4, 5, 6, 7), pi3 = _mm512_setr_epi64(3, 1, 4, 2, 0, 5, 6, 7),
+                  pi4 = _mm512_setr_epi64(4, 2, 0, 3, 1, 5, 6, 7);
+    // pi2 (5x5 transpose) index vectors; +8 selects the second source
+    const __m512i t_s1 = _mm512_setr_epi64(0, 1, 2, 3, 4, 5, 8 + 0, 8 + 2), t_s2 = _mm512_setr_epi64(0, 1, 2, 3, 4, 5, 8 + 1, 8 + 3),
+                  t_bg = _mm512_setr_epi64(0, 1, 8 + 0, 8 + 1, 6, 5, 6, 7), t_km = _mm512_setr_epi64(2, 3, 8 + 2, 8 + 3, 7, 5, 6, 7),
+                  t_s3 = _mm512_setr_epi64(4, 5, 8 + 4, 8 + 5, 4, 5, 6, 7);
+    for (int r = 0; r < 24; r++) {
+        // theta
+        __m512i C = _mm512_ternarylogic_epi64(_mm512_ternarylogic_epi64(P0, P1, P2, 0x96), P3, P4, 0x96);
+        __m512i D = _mm512_xor_si512(_mm512_permutexvar_epi64(prev, C), _mm512_rol_epi64(_mm512_permutexvar_epi64(next, C), 1));
+        // theta + rho
+        P0 = _mm512_rolv_epi64(_mm512_xor_si512(P0, D), rho0); P1 = _mm512_rolv_epi64(_mm512_xor_si512(P1, D), rho1);
+        P2 = _mm512_rolv_epi64(_mm512_xor_si512(P2, D), rho2); P3 = _mm512_rolv_epi64(_mm512_xor_si512(P3, D), rho3);
+        P4 = _mm512_rolv_epi64(_mm512_xor_si512(P4, D), rho4);
+        // pi1
+        __m512i Q0 = _mm512_permutexvar_epi64(pi0, P0), Q1 = _mm512_permutexvar_epi64(pi1, P1), Q2 = _mm512_permutexvar_epi64(pi2, P2),
+                Q3 = _mm512_permutexvar_epi64(pi3, P3), Q4 = _mm512_permutexvar_epi64(pi4, P4);
+        // chi across registers: R_x = Q_x ^ (~Q_{x+1} & Q_{x+2})   (0xD2 = a ^ (~b & c))
+        __m512i R0 = _mm512_ternarylogic_epi64(Q0, Q1, Q2, 0xD2), R1 = _mm512_ternarylogic_epi64(Q1, Q2, Q3, 0xD2),
+                R2 = _mm512_ternarylogic_epi64(Q2, Q3, Q4, 0xD2), R3 = _mm512_ternarylogic_epi64(Q3, Q4, Q0, 0xD2),
+                R4 = _mm512_ternarylogic_epi64(Q4, Q0, Q1, 0xD2);
+        // iota: A[0][0] is element 0 of R0
+        R0 = _mm512_xor_si512(R0, _mm512_maskz_set1_epi64(0x01, (long long)RC[r]));
+        // pi2: transpose back, P_y[x] = R_x[y]
+        __m512i a0 = _mm512_unpacklo_epi64(R0, R1), a1 = _mm512_unpacklo_epi64(R2, R3);
+        __m512i b0 = _mm512_unpackhi_epi64(R0, R1), b1 = _mm512_unpackhi_epi64(R2, R3);
+        a0 = _mm512_permutex2var_epi64(a0, t_s1, R4);      // elements 6,7 <- R4[0], R4[2]
+        b0 = _mm512_permutex2var_epi64(b0, t_s2, R4);      // elements 6,7 <- R4[1], R4[3]
+        P0 = _mm512_permutex2var_epi64(a0, t_bg, a1);
+        P1 = _mm512_permutex2var_epi64(b0, t_bg, b1);
+        P2 = _mm512_permutex2var_epi64(a0, t_km, a1);
+        P3 = _mm512_permutex2var_epi64(b0, t_km, b1);
+        P4 = _mm512_mask_blend_epi64(0x10, _mm512_permutex2var_epi64(a0, t_s3, a1), R4);
+    }
+    _mm512_mask_storeu_epi64(s, m5, P0); _mm512_mask_storeu_epi64(s + 5, m5, P1); _mm512_mask_storeu_epi64(s + 10, m5, P2);
+    _mm512_mask_storeu_epi64(s + 15, m5, P3); _mm512_mask_storeu_epi64(s + 20, m5, P4);
+}
+// Which one is faster depends on the core (measured: AVX-512 wins on Intel Xeon, the scalar code wins on Zen 5 whose
+// cross-lane permutes have a longer latency), so a 1 ms calibration at first use picks the implementation. Both
+// compute the same permutation (tests/test_host_logic.py), the choice never changes an output.
+static inline bool keccak_have_avx512() {
+    static const bool use = [] {
+        if (!__builtin_cpu_supports("avx512f")) return false;
+        uint64_t a[25], b[25];
+        for (int i = 0; i < 25; i++) a[i] = b[i] = 0x9e3779b97f4a7c15ULL * (uint64_t)(i + 1);
+        auto time_it = [](void (*f)(uint64_t *), uint64_t *st) {
+            uint64_t best = ~0ULL;
+            for (int rep = 0; rep < 3; rep++) {
+                uint64_t t0 = __builtin_ia32_rdtsc();
+                for (int r = 0; r < 1500; r++) f(st);
+                uint64_t dt = __builtin_ia32_rdtsc() - t0;
+                if (dt < best) best = dt;
+            }
+            return best;
+        };
+        uint64_t ts = time_it([](uint64_t *st) { keccak_f1600_scalar(st); }, a);
+        uint64_t tv = time_it([](uint64_t *st) { keccak_f1600_avx512(st); }, b);
+        return tv < ts;
+    }();
+    return use;
+}
+static inline void keccak_f1600_host(uint64_t s[25]) { if (keccak_have_avx512()) keccak_f1600_avx512(s); else keccak_f1600_scalar(s); }
+#else
+static inline bool keccak_have_avx512() { return false; }
+static inline void keccak_f1600_host(uint64_t s[25]) { keccak_f1600_scalar(s); }
+#endif
 
 // SHAKE256 squeeze helper for the generator chains, and SHA3-512 for the Pedersen blinding base.
 class Shake256 {

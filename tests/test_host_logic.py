@@ -153,3 +153,12 @@ def test_verifier_side_gadget_sizes():
     bpg.MimcHash256(image).verify(v, [pre], d)
     i = v.instance()
     assert (i.n, i.q, i.m) == (972, 1946, 4)
+
+
+def test_keccak_vector_and_scalar_implementations_agree():
+    import ctypes as C
+    impl, ns = C.c_int32(), C.c_double()
+    for seed in (1, 2, 0xdeadbeef):
+        rc = bpg.lib().bpg_keccak_selftest(C.c_uint64(seed), C.c_uint32(3000), C.byref(impl), None)
+        assert rc == 0, bpg.lib().bpg_last_error()
+    assert impl.value in (0, 1)
