@@ -219,6 +219,12 @@ class Context:
         _chk(lib().bpg_msm_gens(self._h, C.c_uint64(first), C.c_uint64(len(s)), b"".join(s), b"".join(t), out))
         return out.raw
 
+    def test_fe_ops(self, op, a_list, b_list):
+        n = len(a_list)
+        out = _buf(32 * n)
+        _chk(lib().bpg_test_fe_ops(self._h, C.c_int32(op), C.c_uint64(n), b"".join(a_list), b"".join(b_list), out))
+        return [out.raw[32 * i:32 * i + 32] for i in range(n)]
+
     def profile_set(self, mode):
         _chk(lib().bpg_profile_set(self._h, C.c_int32(mode)))
 

@@ -199,6 +199,19 @@ double Engine::bench_fe_mul(uint32_t iters) {
     return (double)blocks * threads * iters * 4.0 / (ms * 1e-3);
 }
 
+void Engine::test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    if (!n) return;
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    I.small_sc.ensure(2 * n * 32); I.comp.ensure(n * 32);
+    HIPCHK(hipMemcpyAsync(I.small_sc.p, a, n * 32, hipMemcpyHostToDevice, I.st));
+    HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + n * 32, b, n * 32, hipMemcpyHostToDevice, I.st));
+    hipLaunchKernelGGL(k_test_fe, dim3(cdiv(n, 64)), dim3(64), 0, I.st, I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + 8 * n, I.comp.as<uint8_t>(), (uint32_t)n, (uint32_t)op);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, I.comp.p, n * 32, hipMemcpyDeviceToHost, I.st));
+    HIPCHK(hipStreamSynchronize(I.st));
+}
+
 void Engine::synchronize() { HIPCHK(hipSetDevice(device_)); HIPCHK(hipStreamSynchronize(impl_->st)); }
 
 // ------------------------------------------------------------------------------------------------ generators

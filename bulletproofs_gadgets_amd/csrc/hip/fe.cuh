@@ -35,6 +35,142 @@ BPG_HD fe fe_fold512(const uint32_t t[16]) {
     return r;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 device paths (inline asm).  The portable C++ forms further down are what the host-side unit tests compile;
+// tests/test_gpu_parity.py::test_device_field_ops checks these against big-integer arithmetic on the GPU itself.
+//
+// Multiply: product scanning with a 96-bit column accumulator (lo = 64-bit VGPR pair, hi = collected carries).
+// v_mad_u64_u32 delivers its carry-out in an SGPR pair and one v_addc collects it: two VALU instructions per limb product
+// and no zero-extension moves (the row-wise C++ form costs ~190 v_mov_b32 per multiplication because every 32-bit limb has
+// to be widened into the MAD's 64-bit addend pair).  Only column 0 (no carry-in) is overflow-free; in every other column
+// the first product initialises hi with its carry (a column's carry-in can reach ~2^35, and (2^32-1)^2 + 2^35 > 2^64).
+__device__ __forceinline__ void fe_mac_first(uint64_t &lo, uint32_t a, uint32_t b) {
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=&s"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fe_mac_second(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t b) {
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2" : "+v"(lo), "=v"(hi), "=&s"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void fe_mac(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t b) {
+    uint64_t c;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(lo), "+v"(hi), "=&s"(c) : "v"(a), "v"(b));
+}
+// r = t[0..7] + 38 * t[8..15] (mod p, weakly reduced): three carry chains
+__device__ __forceinline__ fe fe_fold512_dev(const uint32_t t[16]) {
+    fe r; uint32_t x, top;
+    asm("v_mul_lo_u32 %8, %18, 38\n\tv_add_co_u32_e32 %0, vcc, %10, %8\n\t"
+        "v_mul_lo_u32 %8, %19, 38\n\tv_addc_co_u32_e32 %1, vcc, %11, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %20, 38\n\tv_addc_co_u32_e32 %2, vcc, %12, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %21, 38\n\tv_addc_co_u32_e32 %3, vcc, %13, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %22, 38\n\tv_addc_co_u32_e32 %4, vcc, %14, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %23, 38\n\tv_addc_co_u32_e32 %5, vcc, %15, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %24, 38\n\tv_addc_co_u32_e32 %6, vcc, %16, %8, vcc\n\t"
+        "v_mul_lo_u32 %8, %25, 38\n\tv_addc_co_u32_e32 %7, vcc, %17, %8, vcc\n\t"
+        "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
+        "v_mul_hi_u32 %8, %18, 38\n\tv_add_co_u32_e32 %1, vcc, %1, %8\n\t"
+        "v_mul_hi_u32 %8, %19, 38\n\tv_addc_co_u32_e32 %2, vcc, %2, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %20, 38\n\tv_addc_co_u32_e32 %3, vcc, %3, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %21, 38\n\tv_addc_co_u32_e32 %4, vcc, %4, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %22, 38\n\tv_addc_co_u32_e32 %5, vcc, %5, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %23, 38\n\tv_addc_co_u32_e32 %6, vcc, %6, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %24, 38\n\tv_addc_co_u32_e32 %7, vcc, %7, %8, vcc\n\t"
+        "v_mul_hi_u32 %8, %25, 38\n\tv_addc_co_u32_e32 %9, vcc, %9, %8, vcc\n\t"
+        "v_mul_u32_u24_e32 %9, 38, %9\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\tv_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
+        "v_add_u32_e32 %0, %0, %8"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(x), "=&v"(top)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]),
+          "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]), "v"(t[14]), "v"(t[15]) : "vcc");
+    return r;
+}
+__device__ __forceinline__ fe fe_mul(const fe &a, const fe &b) {
+    uint32_t t[16];
+    uint64_t lo = 0; uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        const int i0 = (k > 7 ? k - 7 : 0), i1 = (k < 7 ? k : 7);
+        hi = 0;
+#pragma unroll
+        for (int i = i0; i <= i1; i++) {
+            if (k == 0) fe_mac_first(lo, a.v[i], b.v[k - i]);                     // no carry-in: cannot overflow
+            else if (i == i0) fe_mac_second(lo, hi, a.v[i], b.v[k - i]);          // carry-in up to ~2^35: may overflow, hi := carry
+            else fe_mac(lo, hi, a.v[i], b.v[k - i]);
+        }
+        t[k] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    }
+    t[15] = (uint32_t)lo;
+    return fe_fold512_dev(t);
+}
+__device__ __forceinline__ fe fe_sq(const fe &a) {
+    // column k: 2 * sum_{i<j, i+j=k} a_i a_j + (k even ? a_{k/2}^2 : 0) + carry of column k-1
+    uint32_t t[16];
+    uint64_t clo = 0;                              // carry from the previous column (< 2^36)
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        const int i0 = (k > 7 ? k - 7 : 0);
+        uint64_t lo = 0; uint32_t hi = 0;
+#pragma unroll
+        for (int i = i0; 2 * i < k; i++) {
+            if (i == i0) fe_mac_first(lo, a.v[i], a.v[k - i]);
+            else if (i == i0 + 1) fe_mac_second(lo, hi, a.v[i], a.v[k - i]);
+            else fe_mac(lo, hi, a.v[i], a.v[k - i]);
+        }
+        hi = (hi << 1) | (uint32_t)(lo >> 63); lo <<= 1;          // double the off-diagonal sum
+        if ((k & 1) == 0) fe_mac(lo, hi, a.v[k / 2], a.v[k / 2]);
+        uint64_t s = lo + clo; hi += (s < lo ? 1u : 0u); lo = s;
+        t[k] = (uint32_t)lo; clo = (lo >> 32) | ((uint64_t)hi << 32);
+    }
+    t[15] = (uint32_t)clo;
+    return fe_fold512_dev(t);
+}
+__device__ __forceinline__ fe fe_add(const fe &a, const fe &b) {
+    fe r; uint32_t t;
+    asm("v_add_co_u32_e32 %0, vcc, %9, %17\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %10, %18, vcc\n\tv_addc_co_u32_e32 %2, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %12, %20, vcc\n\tv_addc_co_u32_e32 %4, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %14, %22, vcc\n\tv_addc_co_u32_e32 %6, vcc, %15, %23, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\tv_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
+        "v_add_u32_e32 %0, %0, %8"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(t)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]) : "vcc");
+    return r;
+}
+__device__ __forceinline__ fe fe_sub(const fe &a, const fe &b) {
+    // a - b, then take 38 back off for each borrow (a - b + 2^256 = a - b + 38 mod p)
+    fe r; uint32_t t;
+    asm("v_sub_co_u32_e32 %0, vcc, %9, %17\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %10, %18, vcc\n\tv_subb_co_u32_e32 %2, vcc, %11, %19, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %12, %20, vcc\n\tv_subb_co_u32_e32 %4, vcc, %13, %21, vcc\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %14, %22, vcc\n\tv_subb_co_u32_e32 %6, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %16, %24, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
+        "v_sub_co_u32_e32 %0, vcc, %0, %8\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, 0, %1, vcc\n\tv_subbrev_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, 0, %3, vcc\n\tv_subbrev_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, 0, %5, vcc\n\tv_subbrev_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+        "v_subbrev_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
+        "v_sub_u32_e32 %0, %0, %8"
+        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(t)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]) : "vcc");
+    return r;
+}
+#else
 BPG_HD fe fe_mul(const fe &a, const fe &b) {
     uint32_t t[16];
     BPG_UNROLL for (int i = 0; i < 16; i++) t[i] = 0;
@@ -73,7 +209,9 @@ BPG_HD fe fe_sq(const fe &a) {
     }
     return fe_fold512(t);
 }
+#endif
 
+#if !defined(__HIP_DEVICE_COMPILE__)
 BPG_HD fe fe_add(const fe &a, const fe &b) {
     fe r; uint64_t c = 0;
     BPG_UNROLL for (int i = 0; i < 8; i++) { c += (uint64_t)a.v[i] + b.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
@@ -94,6 +232,7 @@ BPG_HD fe fe_sub(const fe &a, const fe &b) {
     r.v[0] -= 38u * (uint32_t)(-d);   // second borrow leaves a value just below 2^256: no further borrow
     return r;
 }
+#endif
 
 BPG_HD fe fe_neg(const fe &a) { return fe_sub(fe_zero(), a); }
 

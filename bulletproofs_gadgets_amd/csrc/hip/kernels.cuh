@@ -108,6 +108,27 @@ __global__ void __launch_bounds__(64) k_pedersen(const uint32_t *__restrict__ v,
     ge_compress(out + 32 * (size_t)i, acc);
 }
 
+// unit-test hook for the device field arithmetic (the inline-asm paths cannot be compiled for the host):
+// op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 chain (mixed ops on weakly reduced intermediates); inputs are raw 256-bit values
+__global__ void __launch_bounds__(64) k_test_fe(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint8_t *__restrict__ out, uint32_t n, uint32_t op) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x, y, r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x.v[k] = a[8 * i + k]; y.v[k] = b[8 * i + k]; }
+    switch (op) {
+    case 0: r = fe_mul(x, y); break;
+    case 1: r = fe_sq(x); break;
+    case 2: r = fe_add(x, y); break;
+    case 3: r = fe_sub(x, y); break;
+    case 4: r = fe_invert(x); break;
+    default:
+        for (int k = 0; k < 25; k++) { fe t = fe_sub(fe_mul(x, y), fe_add(x, y)); x = fe_sq(fe_sub(y, t)); y = fe_add(t, fe_neg(x)); }
+        r = fe_add(x, y); break;
+    }
+    fe_tobytes(out + 32 * (size_t)i, r);
+}
+
 // integer-VALU roofline probe: 4 independent chains of field multiplications per thread, nothing but registers
 __global__ void __launch_bounds__(256) k_bench_fe_mul(fe *__restrict__ out, uint32_t iters) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

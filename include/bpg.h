@@ -96,6 +96,8 @@ bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);
 bpg_status bpg_profile_report(bpg_ctx *ctx, char *out, uint64_t cap);
 bpg_status bpg_bench_fe_mul(bpg_ctx *ctx, uint32_t iters, double *mults_per_second);
 
+/* test hook: device field arithmetic on n pairs of raw 256-bit values; op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 mixed chain; canonical output */
+bpg_status bpg_test_fe_ops(bpg_ctx *ctx, int32_t op, uint64_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 /* test hook: compress(sum s_i*G[first+i] + t_i*H[first+i]) through the bucket-method MSM kernels */
 bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
 

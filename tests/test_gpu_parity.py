@@ -59,6 +59,36 @@ class LabeledTranscript(bpg.Transcript):
         self._label = label
 
 
+def test_device_field_ops(ctx):
+    """the gfx950 inline-asm field arithmetic (fe.cuh device paths) against Python big integers, incl. weakly reduced edge values"""
+    P = R.P
+    edge = [0, 1, 2, 19, 37, 38, 39, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**255 - 1, 2**255, 2**256 - 39, 2**256 - 38, 2**256 - 1,
+            2**256 - 2**32, 2**224, (2**256 - 1) ^ (2**128 - 1), 2**32 - 1, 2**64 - 1, (2**256 - 1) // 3]
+    vals = edge + [int.from_bytes(hashlib.sha256(b"fe%d" % i).digest(), "little") for i in range(400)]
+    A = [v.to_bytes(32, "little") for v in vals for _ in range(3)]
+    Bv = []
+    for i, v in enumerate(vals):
+        Bv += [vals[(7 * i + 3) % len(vals)], vals[(13 * i + 5) % len(vals)], edge[i % len(edge)]]
+    B = [v.to_bytes(32, "little") for v in Bv]
+    av = [int.from_bytes(x, "little") for x in A]
+    ops = {0: lambda a, b: a * b, 1: lambda a, b: a * a, 2: lambda a, b: a + b, 3: lambda a, b: a - b}
+    for op, f in ops.items():
+        got = ctx.test_fe_ops(op, A, B)
+        for a, b, g in zip(av, Bv, got):
+            assert int.from_bytes(g, "little") == f(a, b) % P, (op, hex(a), hex(b))
+    got = ctx.test_fe_ops(4, A[:120], B[:120])
+    for a, g in zip(av[:120], got):
+        assert int.from_bytes(g, "little") == pow(a % P, P - 2, P)
+    got = ctx.test_fe_ops(5, A[:200], B[:200])
+    for a, b, g in zip(av[:200], Bv[:200], got):
+        x, y = a % P, b % P
+        for _ in range(25):
+            t = (x * y - (x + y)) % P
+            x = (y - t) ** 2 % P
+            y = (t - x) % P
+        assert int.from_bytes(g, "little") == (x + y) % P
+
+
 def test_pedersen_bases_and_commitments(ctx, golden):
     B, Bb = ctx.pedersen_bases()
     assert B.hex() == golden["pedersen"]["B"] and Bb.hex() == golden["pedersen"]["B_blinding"]
