@@ -308,3 +308,61 @@ def test_combine_gadgets(ctx):
         bpg.MimcHash256(wv[1]).verify(v, [wv[0]], bpg.verifier_commit(v, hdc))
         bpg.MerkleTree256(root, [leaf], [wv[1]], "(W I)").verify(v, [], [])
     check_against_oracle(ctx, p, t, w1_com + [w2_com] + bdc + hdc, 8192, replay)
+
+
+def test_cfg3_mimc_preimage_2_16(ctx):
+    """BASELINE.json config 3: one HASH over a 2,130-byte preimage -> 67 absorbed blocks, n = 65,124, N = 2^16, q = 130,250."""
+    a = workloads.mimc_preimage(ctx, nbytes=2130, seed=0, label=b"MiMCHash")
+    a.transcript._label = b"MiMCHash"
+    inst = a.prover.instance()
+    assert (inst.n, a.gens_capacity, inst.q, inst.m) == (65124, 65536, 130250, 69)
+    ctx.gens_ensure(65536)
+    G, Hh = ctx.gens_export(0, 65536)
+    og = O.Gens(compressed=(G, Hh))            # GPU generators (checked against the oracle's derivation in test_generators_*)
+    assert og.export(65000, 100) == O.Gens(65100).export(65000, 100)
+    check_against_oracle(ctx, a.prover, a.transcript, a.commitments, 65536, a.replay, ogens=og)
+
+
+def test_cfg4_full_merkle_2_20_roundtrip(ctx):
+    """BASELINE.json config 4 at full size: the reference's own 2^20 circuit (merkle_tree_gadget.rs:473-545). The oracle prover
+    would need minutes, so the size-independent property is used: the GPU proof must be accepted by the oracle VERIFIER (one
+    2N-term MSM on the CPU) run on the verifier-side assembly, and a tampered proof / wrong root must be rejected."""
+    a = workloads.merkle_full_tree(ctx, leaves=512, seed=None, label=b"MerkleTree")
+    inst = a.prover.instance()
+    assert (inst.n, a.gens_capacity, inst.q, inst.m) == (993384, 1048576, 1986769, 512)
+    state = a.transcript.state
+    proof = a.prover.prove(bpg.BulletproofGens(ctx, a.gens_capacity), bytes(range(32)))
+    assert len(proof) == 14 * 32 + (2 * 20 + 2) * 32 == 1792
+    G, Hh = ctx.gens_export(0, a.gens_capacity)
+    og = O.Gens(compressed=(G, Hh))
+    sample = O.Gens(4096)
+    assert og.export(0, 4096) == sample.export(0, 4096)
+    tv = bpg.Transcript(b"MerkleTree")
+    v = bpg.Verifier(tv)
+    a.replay(v)
+    vi = v.instance()
+    assert tv.state == state and v.get_num_vars() == inst.n
+    vc = to_oracle(vi)
+    assert O.verify(og, tv.state, vc, b"".join(a.commitments), proof) == 0
+    bad = bytearray(proof); bad[700] ^= 0x40
+    assert O.verify(og, tv.state, vc, b"".join(a.commitments), bytes(bad)) != 0
+    # determinism: same seed -> same bytes; different seed -> different proof that still verifies
+    res = ctx.upload(inst)
+    p2, _ = res.prove(state, inst.v_blinding, bytes(range(32)))
+    p3, _ = res.prove(state, inst.v_blinding, bytes(32))
+    res.free()
+    assert p2 == proof and p3 != proof
+    assert O.verify(og, tv.state, vc, b"".join(a.commitments), p3) == 0
+
+
+def test_skewed_witness_distributions(ctx):
+    """range-proof style witnesses (bits) and constant vectors put most MSM terms into a handful of buckets"""
+    t = LabeledTranscript(b"skew")
+    p = bpg.Prover(ctx, t)
+    x = (2**200 - 12345).to_bytes(32, "little")
+    cs, vs = p.commit_many([x], [rs(b"sk", 0)])
+    bpg.range_proof(p, vs[0], 200, x)
+    for _ in range(300):                       # 300 multipliers with identical assignments
+        l, r, o = p.allocate_multiplier((sc(7), sc(9)))
+        p.constrain(bpg.LinearCombination.of(o) - sc(63))
+    check_against_oracle(ctx, p, t, cs, 512)
