@@ -239,6 +239,10 @@ class Context:
         _chk(lib().bpg_bench_fe_mul(self._h, C.c_uint32(iters), C.byref(r)))
         return r.value
 
+    def verify_flat(self, inst: "FlatInstance", transcript_state, commitments, proof, seed=bytes(32), flags=0):
+        """bpg_r1cs_verify: 0 = accepted, 3 = VERIFICATION_ERROR, 2 = FORMAT_ERROR, 1 = INVALID_GENERATORS_LENGTH."""
+        return _verify_flat(self, inst, transcript_state, commitments, proof, seed, flags)
+
     # ---- PART 1 boundary on flattened instances
     def upload(self, inst: "FlatInstance"):
         h = C.c_void_p()
@@ -253,6 +257,13 @@ class Context:
         cs = inst.cstruct()
         _chk(lib().bpg_r1cs_prove(self._h, C.byref(cs), ts, C.c_uint64(inst.m), v_blinding, rng_seed, C.c_uint32(flags), out, C.byref(ln)))
         return out.raw[:ln.value], ts.raw[:203]
+
+
+def _verify_flat(ctx, inst, transcript_state, commitments, proof, seed=bytes(32), flags=0):
+    ts = _buf(203); ts.raw = bytes(transcript_state)
+    cs = inst.cstruct()
+    cs.aL = cs.aR = cs.aO = None
+    return lib().bpg_r1cs_verify(ctx._h, C.byref(cs), ts, C.c_uint64(inst.m), commitments, proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags))
 
 
 class ResidentCircuit:
@@ -413,6 +424,20 @@ class Verifier:
         return Variable(var.value)
 
     def get_num_vars(self): return lib().bpg_verifier_num_vars(self._h)
+
+    def verify(self, proof: bytes, ctx: "Context", bp_gens, seed: bytes = bytes(32), flags: int = 0):
+        """Verifier::verify(&proof, &pc_gens, &bp_gens) on the GPU: returns None, raises BpgError(VERIFICATION_ERROR / FORMAT_ERROR ...)."""
+        capacity = bp_gens.gens_capacity if isinstance(bp_gens, BulletproofGens) else int(bp_gens)
+        _chk(lib().bpg_verifier_verify(self._h, ctx._h, C.c_uint64(capacity), proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags)))
+
+    def is_valid(self, proof, ctx, bp_gens, seed=bytes(32), flags=0):
+        try:
+            self.verify(proof, ctx, bp_gens, seed, flags)
+            return True
+        except BpgError as e:
+            if e.status in (2, 3):
+                return False
+            raise
 
     def instance(self) -> FlatInstance:
         view, coms = R1CSInstance(), C.c_void_p()

@@ -101,11 +101,12 @@ static void view(const FlatCircuit &f, bpg_r1cs_instance *o) {
     o->aL = f.aL.empty() ? nullptr : f.aL.data(); o->aR = f.aR.empty() ? nullptr : f.aR.data(); o->aO = f.aO.empty() ? nullptr : f.aO.data();
     o->row_ptr = f.row_ptr.data(); o->term_var = f.term_var.data(); o->term_coef = f.term_coef.data(); o->coef = f.coef.data();
 }
-static FlatCircuit from_view(const bpg_r1cs_instance *i) {
+static FlatCircuit from_view(const bpg_r1cs_instance *i, bool need_witness = true) {
     REQUIRE(i && i->row_ptr && (i->nnz == 0 || (i->term_var && i->term_coef)) && (i->ncoef == 0 || i->coef));
-    REQUIRE(i->n == 0 || (i->aL && i->aR && i->aO));
+    const bool has_w = i->aL && i->aR && i->aO;
+    REQUIRE(i->n == 0 || has_w || !need_witness);
     FlatCircuit f; f.n = i->n; f.m = i->m;
-    f.aL.assign(i->aL, i->aL + i->n * 32); f.aR.assign(i->aR, i->aR + i->n * 32); f.aO.assign(i->aO, i->aO + i->n * 32);
+    if (has_w) { f.aL.assign(i->aL, i->aL + i->n * 32); f.aR.assign(i->aR, i->aR + i->n * 32); f.aO.assign(i->aO, i->aO + i->n * 32); }
     f.row_ptr.assign(i->row_ptr, i->row_ptr + i->q + 1);
     f.term_var.assign(i->term_var, i->term_var + i->nnz); f.term_coef.assign(i->term_coef, i->term_coef + i->nnz);
     f.coef.assign(i->coef, i->coef + i->ncoef * 32);
@@ -206,6 +207,23 @@ bpg_status bpg_r1cs_prove(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t t
     return s;
 }
 
+bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t ts[BPG_TRANSCRIPT_STATE_BYTES], uint64_t m, const uint8_t *V,
+                           const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags) {
+    return guard([&] {
+        REQUIRE(ctx && ts && proof && seed && (m == 0 || V));
+        FlatCircuit f = from_view(inst, false);
+        if (f.m != m) throw std::invalid_argument("verify: m does not match the instance");
+        f.aL.clear(); f.aR.clear(); f.aO.clear();
+        DeviceCircuit *dc = ctx->engine->upload(f);
+        Transcript T = Transcript::from_state(ts);
+        R1CSError e;
+        try { e = ctx->engine->verify(dc, T, V, proof, proof_len, seed, flags); } catch (...) { ctx->engine->free_circuit(dc); throw; }
+        ctx->engine->free_circuit(dc);
+        T.export_state(ts);
+        if (e != R1CSError::None) throw R1CSException(e, e == R1CSError::VerificationError ? "proof rejected" : e == R1CSError::FormatError ? "malformed proof" : "generator capacity below padded circuit size");
+    });
+}
+
 // ---------------------------------------------------------------------------------------- transcript
 bpg_status bpg_transcript_new(const uint8_t *label, uint64_t len, bpg_transcript **out) {
     return guard([&] { REQUIRE(out && (len == 0 || label)); *out = new bpg_transcript{Transcript(label, len)}; });
@@ -292,6 +310,21 @@ bpg_status bpg_verifier_commit(bpg_verifier *v, const uint8_t com[32], uint32_t 
 uint64_t bpg_verifier_num_vars(const bpg_verifier *v) { return v ? v->v->get_num_vars() : 0; }
 bpg_status bpg_verifier_instance(bpg_verifier *v, bpg_r1cs_instance *out, const uint8_t **commitments_out) {
     return guard([&] { REQUIRE(v && out); v->flat = v->v->flatten(); view(v->flat, out); if (commitments_out) *commitments_out = v->v->commitments().data(); });
+}
+
+bpg_status bpg_verifier_verify(bpg_verifier *v, bpg_ctx *ctx, uint64_t gens_capacity, const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags) {
+    return guard([&] {
+        REQUIRE(v && ctx && proof && seed);
+        ctx->engine->gens_ensure(gens_capacity);
+        uint64_t N = 1; while (N < v->v->get_num_vars()) N <<= 1;
+        if (gens_capacity < N) throw R1CSException(R1CSError::InvalidGeneratorsLength, "generator capacity below padded circuit size");
+        FlatCircuit f = v->v->flatten();
+        DeviceCircuit *dc = ctx->engine->upload(f);
+        R1CSError e;
+        try { e = ctx->engine->verify(dc, *v->v->transcript(), v->v->commitments().data(), proof, proof_len, seed, flags); } catch (...) { ctx->engine->free_circuit(dc); throw; }
+        ctx->engine->free_circuit(dc);
+        if (e != R1CSError::None) throw R1CSException(e, e == R1CSError::VerificationError ? "proof rejected" : e == R1CSError::FormatError ? "malformed proof" : "generator capacity below padded circuit size");
+    });
 }
 
 // ---------------------------------------------------------------------------------------- gadgets

@@ -77,6 +77,7 @@ uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; re
 
 struct DeviceCircuit {
     uint64_t n = 0, m = 0, q = 0, ncols = 0, nnz = 0;
+    bool has_witness = false;
     DevBuf aL, aR, aO, col_ptr, ent_row, ent_coef, coef;
 };
 
@@ -84,7 +85,7 @@ struct DeviceCircuit {
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_digits_count) X(k_msm_digits_scatter) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_bench_fe_mul)
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -124,7 +125,7 @@ struct Engine::Impl {
     DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums;
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
-    DevBuf ipa_s, ipa_tabA, ipa_tabB, naf;
+    DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     PinBuf h_raw, h_small;
     uint64_t gens_cap = 0;
 
@@ -158,7 +159,7 @@ Engine::~Engine() {
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums};
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release();
     (void)hipStreamDestroy(impl_->st);
@@ -370,17 +371,19 @@ DeviceCircuit *Engine::upload(const FlatCircuit &c) {
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
     const uint64_t n = c.n, m = c.m, q = c.row_ptr.size() - 1, nnz = c.term_var.size(), ncoef = c.coef.size() / 32;
-    if (c.aL.size() != n * 32 || c.aR.size() != n * 32 || c.aO.size() != n * 32) throw std::invalid_argument("upload: witness vectors must hold n scalars");
+    const bool has_witness = !(c.aL.empty() && c.aR.empty() && c.aO.empty() && n > 0);
+    if (has_witness && (c.aL.size() != n * 32 || c.aR.size() != n * 32 || c.aO.size() != n * 32)) throw std::invalid_argument("upload: witness vectors must hold n scalars");
     if (c.row_ptr.front() != 0 || c.row_ptr.back() != nnz || c.term_coef.size() != nnz) throw std::invalid_argument("upload: malformed CSR");
     if (n >= (1u << 27)) throw std::invalid_argument("upload: too many multipliers");
-    // CSR (by constraint) -> CSC (by variable) on the host; columns: [0,n) left, [n,2n) right, [2n,3n) output, [3n,3n+m) committed
-    const uint64_t ncols = 3 * n + m;
+    // CSR (by constraint) -> CSC (by variable) on the host; columns: [0,n) left, [n,2n) right, [2n,3n) output, [3n,3n+m) committed,
+    // 3n+m = the constant terms (Variable::One; only the verifier's w_c needs them)
+    const uint64_t ncols = 3 * n + m + 1;
     std::vector<uint64_t> col_ptr(ncols + 1, 0);
     auto col_of = [&](uint32_t pv) -> int64_t {
         uint32_t kind = pv >> 29, idx = pv & 0x1fffffffu;
         if (kind <= 2) { if (idx >= n) throw std::invalid_argument("upload: multiplier index out of range"); return (int64_t)(kind * n + idx); }
         if (kind == 3) { if (idx >= m) throw std::invalid_argument("upload: committed index out of range"); return (int64_t)(3 * n + idx); }
-        if (kind == 4) return -1;                       // Variable::One: ignored by the prover
+        if (kind == 4) return (int64_t)(3 * n + m);
         throw std::invalid_argument("upload: bad variable kind");
     };
     for (uint64_t k = 0; k < nnz; k++) {
@@ -397,7 +400,7 @@ DeviceCircuit *Engine::upload(const FlatCircuit &c) {
             uint64_t pos = fill[col]++; ent_row[pos] = (uint32_t)r; ent_coef[pos] = c.term_coef[k];
         }
     DeviceCircuit *d = new DeviceCircuit();
-    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept;
+    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept; d->has_witness = has_witness;
     try {
         d->aL.ensure((n ? n : 1) * sizeof(scm)); d->aR.ensure((n ? n : 1) * sizeof(scm)); d->aO.ensure((n ? n : 1) * sizeof(scm));
         d->col_ptr.ensure((ncols + 1) * 8); d->ent_row.ensure(ent_row.size() * 4); d->ent_coef.ensure(ent_coef.size() * 4);
@@ -408,7 +411,7 @@ DeviceCircuit *Engine::upload(const FlatCircuit &c) {
         DevBuf *dst[4] = {&d->aL, &d->aR, &d->aO, &d->coef};
         const uint64_t cnts[4] = {n, n, n, ncoef};
         for (int k = 0; k < 4; k++) {
-            if (!cnts[k]) continue;
+            if (!cnts[k] || (k < 3 && !has_witness)) continue;
             HIPCHK(hipMemcpyAsync(I.small_sc.p, src[k]->data(), cnts[k] * 32, hipMemcpyHostToDevice, I.st));
             BPG_LAUNCH(I, k_sc_from_bytes, dim3(cdiv(cnts[k], 256)), dim3(256), I.small_sc.as<uint32_t>(), dst[k]->as<scm>(), (uint32_t)cnts[k]);
             HIPCHK(hipGetLastError());
@@ -438,6 +441,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     hipStream_t st = I.st;
     const uint64_t n = c->n, m = c->m, q = c->q;
     if (v_blinding.size() != m) throw std::invalid_argument("prove: need one blinding factor per committed variable");
+    if (!c->has_witness) throw R1CSException(R1CSError::MissingAssignment, "prove: the uploaded circuit carries no assignments (verifier-side instance)");
     uint64_t N = 1; while (N < n) N <<= 1;
     const uint32_t lgN = ceil_log2(N);
     if (gens_cap_ < N) throw R1CSException(R1CSError::InvalidGeneratorsLength, "generator capacity below padded circuit size");
@@ -650,6 +654,139 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     { uint8_t o[64]; from_scm(ab[0]).to_bytes(o); from_scm(ab[1]).to_bytes(o + 32); proof.insert(proof.end(), o, o + 64); }
     if (tm) { tm->ipa = tm->ipa_msm + tm->ipa_fold; tm->total += now_ms() - t_begin; }
     return proof;
+}
+
+// ------------------------------------------------------------------------------------------------ verify
+// Verifier::verify (dalek r1cs/verifier.rs; reference call site src/bin/verifier.rs:89-90): Fiat-Shamir replay on the host,
+// then ONE multiscalar multiplication of 2N + m + 2 lgN + 13 terms through the same bucket-method kernels; accept iff it is the identity.
+R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, const uint8_t *proof, size_t proof_len, const uint8_t seed[32], uint32_t flags) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    hipStream_t st = I.st;
+    const uint64_t n = c->n, m = c->m, q = c->q;
+    uint64_t N = 1; while (N < n) N <<= 1;
+    const uint32_t lgN = ceil_log2(N);
+    const bool compact = flags & 1u, no_1phase = flags & 2u;
+    const size_t need = (compact ? 1 + 11 * 32 : 14 * 32) + (2 * (size_t)lgN + 2) * 32;
+    if (proof_len != need) return R1CSError::FormatError;
+    if (gens_cap_ < N) return R1CSError::InvalidGeneratorsLength;
+    if (lgN > 32) return R1CSError::FormatError;
+    const uint8_t *in = proof;
+    static const uint8_t ident[32] = {0};
+    if (compact) { if (*in++ != 0) return R1CSError::FormatError; }
+    const uint8_t *pA[6] = {in, in + 32, in + 64, ident, ident, ident}; in += 96;
+    if (!compact) { pA[3] = in; pA[4] = in + 32; pA[5] = in + 64; in += 96; }
+    const uint8_t *pT[5]; for (int k = 0; k < 5; k++) { pT[k] = in; in += 32; }
+    Scalar sc5[5];                                   // t_x, t_x_blinding, e_blinding, a, b : must be canonical (R1CSProof::from_bytes)
+    const uint8_t *ps[5] = {in, in + 32, in + 64, proof + proof_len - 64, proof + proof_len - 32};
+    for (int k = 0; k < 5; k++) { std::memcpy(sc5[k].w, ps[k], 32); if (!sc5[k].is_canonical()) return R1CSError::FormatError; }
+    in += 96;
+    const uint8_t *pLR = in;
+    const Scalar &tx = sc5[0], &txb = sc5[1], &eb = sc5[2], &ipa = sc5[3], &ipb = sc5[4];
+    auto is_ident = [](const uint8_t *p) { return std::memcmp(p, ident, 32) == 0; };
+
+    T.append_u64("m", m);
+    if (is_ident(pA[0]) || is_ident(pA[1]) || is_ident(pA[2])) return R1CSError::VerificationError;      // validate_and_append_point
+    T.append_point("A_I1", pA[0]); T.append_point("A_O1", pA[1]); T.append_point("S1", pA[2]);
+    if (!no_1phase) T.r1cs_1phase_domain_sep();
+    T.append_point("A_I2", pA[3]); T.append_point("A_O2", pA[4]); T.append_point("S2", pA[5]);
+    const Scalar y = T.challenge_scalar("y"), z = T.challenge_scalar("z");
+    static const char *tl[5] = {"T_1", "T_3", "T_4", "T_5", "T_6"};
+    for (int k = 0; k < 5; k++) { if (is_ident(pT[k])) return R1CSError::VerificationError; T.append_point(tl[k], pT[k]); }
+    const Scalar u_ch = T.challenge_scalar("u"), x = T.challenge_scalar("x");
+    T.append_scalar("t_x", tx); T.append_scalar("t_x_blinding", txb); T.append_scalar("e_blinding", eb);
+    const Scalar w = T.challenge_scalar("w");
+    T.innerproduct_domain_sep(N);
+    std::vector<Scalar> uk(lgN), ukinv(lgN);
+    bool lr_ident = false;
+    for (uint32_t k = 0; k < lgN; k++) {
+        const uint8_t *L = pLR + 64 * k, *R = L + 32;
+        lr_ident |= is_ident(L) || is_ident(R);
+        T.append_point("L", L); T.append_point("R", R);
+        uk[k] = T.challenge_scalar("u"); ukinv[k] = uk[k];
+    }
+    if (lr_ident) return R1CSError::VerificationError;
+    if (lgN) Scalar::batch_invert(ukinv);
+    TranscriptRng rng = T.build_rng({}, seed);
+    const Scalar r = rng.random_scalar();
+    const Scalar yinv = y.invert();
+
+    // ---- device side
+    const uint32_t npts = (uint32_t)(6 + m + 5 + 2 * lgN);
+    std::vector<uint8_t> hpts((size_t)npts * 32);
+    {
+        size_t o = 0;
+        for (int k = 0; k < 6; k++) { std::memcpy(&hpts[o], pA[k], 32); o += 32; }
+        if (m) { std::memcpy(&hpts[o], V, m * 32); o += m * 32; }
+        for (int k = 0; k < 5; k++) { std::memcpy(&hpts[o], pT[k], 32); o += 32; }
+        for (uint32_t k = 0; k < lgN; k++) { std::memcpy(&hpts[o], pLR + 64 * k, 32); o += 32; }
+        for (uint32_t k = 0; k < lgN; k++) { std::memcpy(&hpts[o], pLR + 64 * k + 32, 32); o += 32; }
+    }
+    I.vfy_in.ensure((size_t)npts * 32); I.vfy_pts.ensure((size_t)npts * sizeof(ge_niels)); I.vfy_ok.ensure((size_t)npts * 4);
+    I.vfy_sc.ensure((size_t)(npts + 2) * sizeof(scm)); I.vfy_ch.ensure(sizeof(IpaChallenges));
+    HIPCHK(hipMemcpyAsync(I.vfy_in.p, hpts.data(), hpts.size(), hipMemcpyHostToDevice, st));
+    BPG_LAUNCH(I, k_decompress, dim3(cdiv(npts, 64)), dim3(64), I.vfy_in.as<uint8_t>(), I.vfy_pts.as<ge_niels>(), I.vfy_ok.as<uint32_t>(), npts);
+    I.yinvpow.ensure(N * sizeof(scm)); I.zpow.ensure((q + 2) * sizeof(scm)); I.wAll.ensure(c->ncols * sizeof(scm));
+    auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
+        uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
+        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
+    };
+    exp_table(yinv, I.yinvpow.as<scm>(), N);
+    exp_table(z, I.zpow.as<scm>(), q + 1);
+    BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(),
+               c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)c->ncols, (uint32_t)(3 * n));
+    scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;      // wV[m] = w_c
+    {
+        I.h_small.ensure(1 << 16);
+        IpaChallenges *hc = reinterpret_cast<IpaChallenges *>(I.h_small.as<uint8_t>() + 8192);
+        for (uint32_t k = 0; k < lgN; k++) { hc->u[k] = to_scm(uk[k]); hc->uinv[k] = to_scm(ukinv[k]); }
+        HIPCHK(hipMemcpyAsync(I.vfy_ch.p, hc, sizeof(IpaChallenges), hipMemcpyHostToDevice, st));
+    }
+    I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm)); I.ypow.ensure(N * sizeof(scm));
+    scm *svec = I.ypow.as<scm>(), *gsc = I.lv.as<scm>(), *hsc = I.rv.as<scm>();
+    BPG_LAUNCH(I, k_ipa_s, dim3(cdiv(N, 256)), dim3(256), I.vfy_ch.as<IpaChallenges>(), svec, lgN, (uint32_t)N);
+    const uint32_t blocks = std::min<uint32_t>(cdiv(N, 256), 1024);
+    I.red_partial.ensure((size_t)blocks * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
+    BPG_LAUNCH(I, k_verify_scalars, dim3(blocks), dim3(256), wL, wR, wO, I.yinvpow.as<scm>(), svec, to_scm(x), to_scm(ipa), to_scm(ipb), to_scm(u_ch),
+               gsc, hsc, I.red_partial.as<scm>(), (uint32_t)n, (uint32_t)N);
+    BPG_LAUNCH(I, k_reduce_partials, dim3(1), dim3(256), I.red_partial.as<scm>(), blocks, 1u, I.red_out.as<scm>());
+    HIPCHK(hipGetLastError());
+    scm h_delta; std::vector<scm> h_wV(m + 1); std::vector<uint32_t> h_ok(npts);
+    HIPCHK(hipMemcpyAsync(&h_delta, I.red_out.p, sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_wV.data(), wV, (m + 1) * sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h_ok.data(), I.vfy_ok.p, npts * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t k = 0; k < npts; k++) if (!h_ok[k]) return R1CSError::VerificationError;      // optional_multiscalar_mul: a point failed to decompress
+    const Scalar delta = from_scm(h_delta), wc = from_scm(h_wV[m]);
+    const Scalar xx = x * x, rxx = r * xx, xxx = x * xx;
+    std::vector<scm> hs(npts + 2);
+    {
+        size_t o = 0;
+        hs[o++] = to_scm(x); hs[o++] = to_scm(xx); hs[o++] = to_scm(xxx);
+        hs[o++] = to_scm(u_ch * x); hs[o++] = to_scm(u_ch * xx); hs[o++] = to_scm(u_ch * xxx);
+        for (uint64_t j = 0; j < m; j++) hs[o++] = to_scm(from_scm(h_wV[j]) * rxx);
+        hs[o++] = to_scm(r * x); hs[o++] = to_scm(rxx * x); hs[o++] = to_scm(rxx * xx); hs[o++] = to_scm(rxx * xxx); hs[o++] = to_scm(rxx * xx * xx);
+        for (uint32_t k = 0; k < lgN; k++) hs[o++] = to_scm(uk[k] * uk[k]);
+        for (uint32_t k = 0; k < lgN; k++) hs[o++] = to_scm(ukinv[k] * ukinv[k]);
+        hs[o++] = to_scm(w * (tx - ipa * ipb) + r * (xx * (wc + delta) - tx));      // B
+        hs[o++] = to_scm(-eb - r * txb);                                              // B_blinding
+    }
+    HIPCHK(hipMemcpyAsync(I.vfy_sc.p, hs.data(), hs.size() * sizeof(scm), hipMemcpyHostToDevice, st));
+    I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
+    {
+        MsmSegs S = seg_new();
+        seg_push(S, gsc, I.gens.as<ge_niels>(), (uint32_t)N, 0);
+        seg_push(S, hsc, I.gens.as<ge_niels>() + gens_cap_, (uint32_t)N, 0);
+        seg_push(S, I.vfy_sc.as<scm>(), I.vfy_pts.as<ge_niels>(), npts, 0);
+        seg_push(S, I.vfy_sc.as<scm>() + npts, I.bases.as<ge_niels>(), 2, 0);
+        I.msm(S, 1, I.msm_result.as<ge_ext>());
+    }
+    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
+    HIPCHK(hipGetLastError());
+    uint8_t out[32];
+    HIPCHK(hipMemcpyAsync(out, I.comp.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return is_ident(out) ? R1CSError::None : R1CSError::VerificationError;
 }
 
 }  // namespace bpg

@@ -43,6 +43,9 @@ public:
     std::vector<uint8_t> prove(DeviceCircuit *c, Transcript &transcript, const std::vector<Scalar> &v_blinding,
                                const uint8_t rng_seed[32], uint32_t flags, ProveTimings *timings = nullptr);
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
+    // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.
+    R1CSError verify(DeviceCircuit *c, Transcript &transcript, const uint8_t *V, const uint8_t *proof, size_t proof_len,
+                     const uint8_t seed[32], uint32_t flags);
     void synchronize();
     // HIP-event profile on the engine's own stream: mode 0 off, 1 = dominant kernel (k_fold_points) only, 2 = all kernels
     void profile_set(int mode);

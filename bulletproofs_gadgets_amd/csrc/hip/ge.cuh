@@ -63,6 +63,16 @@ BPG_HD ge_ext ge_dbl(const ge_ext &p) {
     return r;
 }
 
+// doubling whose result only feeds another doubling: T is never read, 4S + 3M
+BPG_HD ge_ext ge_dbl_noT(const ge_ext &p) {
+    fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ2 = fe_sq(p.Z); ZZ2 = fe_add(ZZ2, ZZ2);
+    fe S = fe_sq(fe_add(p.X, p.Y));
+    fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    fe cX = fe_sub(S, YpX), cT = fe_sub(ZZ2, YmX);
+    ge_ext r; r.X = fe_mul(cX, cT); r.Y = fe_mul(YpX, YmX); r.Z = fe_mul(YmX, cT); r.T = p.T;
+    return r;
+}
+
 // extended -> affine Niels given 1/Z
 BPG_HD ge_niels ge_to_niels(const ge_ext &p, const fe &zinv) {
     fe x = fe_mul(p.X, zinv), y = fe_mul(p.Y, zinv);
@@ -99,6 +109,26 @@ BPG_HD void ge_compress(uint8_t *out, const ge_ext &p) {
     Y = fe_cneg(Y, fe_isnegative(fe_mul(X, zinv)));
     fe s = fe_abs(fe_mul(den, fe_sub(p.Z, Y)));
     fe_tobytes(out, s);
+}
+
+// RFC 9496 4.3.1 Decode: returns 1 and the point when s is a canonical, non-negative encoding of a group element
+BPG_HD uint32_t ge_decompress(ge_ext &p, const uint8_t *in) {
+    fe s = fe_frombytes(in);
+    uint8_t chk[32]; fe_tobytes(chk, s);
+    uint32_t canonical = 1;
+    for (int i = 0; i < 32; i++) canonical &= (chk[i] == in[i]);         // also rejects bit 255 set
+    const fe one = fe_one();
+    fe ss = fe_sq(s);
+    fe u1 = fe_sub(one, ss), u2 = fe_add(one, ss);
+    fe u2s = fe_sq(u2);
+    fe v = fe_sub(fe_neg(fe_mul(FE_D(), fe_sq(u1))), u2s);
+    fe I; uint32_t ok = fe_sqrt_ratio_i(I, one, fe_mul(v, u2s));
+    fe Dx = fe_mul(I, u2), Dy = fe_mul(fe_mul(I, Dx), v);
+    fe x = fe_abs(fe_mul(fe_add(s, s), Dx));
+    fe y = fe_mul(u1, Dy);
+    fe t = fe_mul(x, y);
+    p.X = x; p.Y = y; p.Z = one; p.T = t;
+    return canonical & (fe_isnegative(s) ^ 1u) & ok & (fe_isnegative(t) ^ 1u) & (fe_iszero(y) ^ 1u);
 }
 
 // RFC 9496 4.3.4 one-way map (dalek elligator_ristretto_flavor)

@@ -90,6 +90,13 @@ bpg_status bpg_r1cs_prove(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t t
                           uint8_t *proof_out, uint64_t *proof_len);
 uint64_t bpg_proof_size(uint64_t n_multipliers, uint32_t flags);
 
+/* replaces R1CSProof::from_bytes + Verifier::verify(&proof, &pc_gens, &bp_gens)   (reference src/bin/verifier.rs:64,89-90).
+ * inst: the verifier-side instance (aL/aR/aO NULL, constraints as assembled with None assignments); transcript_state: Merlin
+ * state after Verifier::new and every "V" append (updated in place); V: the m commitments; seed replaces the verifier's
+ * thread_rng() draw. Returns BPG_OK, BPG_ERR_VERIFICATION, BPG_ERR_FORMAT or BPG_ERR_INVALID_GENERATORS_LENGTH. */
+bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
+                           uint64_t m, const uint8_t *V, const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags);
+
 /* measurement hooks (bench.py): HIP events on the engine's own stream. mode 0 off, 1 = dominant kernel only, 2 = all kernels;
  * report = JSON text {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}} accumulated since the last set. */
 bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);
@@ -139,6 +146,9 @@ void bpg_verifier_free(bpg_verifier *v);
 bpg_status bpg_verifier_commit(bpg_verifier *v, const uint8_t com[32], uint32_t *var_out);       /* Verifier::commit */
 uint64_t bpg_verifier_num_vars(const bpg_verifier *v);                                          /* fork getter, verifier.rs:89 */
 bpg_status bpg_verifier_instance(bpg_verifier *v, bpg_r1cs_instance *out, const uint8_t **commitments_out);
+/* Verifier::verify(&proof, &pc_gens, &bp_gens) on the GPU of ctx */
+bpg_status bpg_verifier_verify(bpg_verifier *v, bpg_ctx *ctx, uint64_t gens_capacity, const uint8_t *proof, uint64_t proof_len,
+                               const uint8_t seed[32], uint32_t flags);
 
 bpg_status bpg_bounds_check_new(const uint8_t *min_be, uint64_t min_len, const uint8_t *max_be, uint64_t max_len, bpg_gadget **out);
 bpg_status bpg_mimc_hash256_new(const bpg_lc *image, bpg_gadget **out);

@@ -47,7 +47,20 @@ def check_against_oracle(ctx, prover, transcript, commitments, capacity, replay=
         assert rc == 0
         assert proof == want, "flags=%d: GPU proof bytes differ from the oracle" % flags
         assert st_after == st_want
-        assert O.verify(ogens, vstate or state, vcirc or oc, b"".join(commitments), proof, flags=flags) == 0
+        coms = b"".join(commitments)
+        assert O.verify(ogens, vstate or state, vcirc or oc, coms, proof, flags=flags) == 0
+        # the GPU verifier (bpg_r1cs_verify) must take the same decisions as the oracle verifier
+        vinst = vi if replay is not None else inst
+        assert ctx.verify_flat(vinst, vstate or state, coms, proof, flags=flags) == 0
+        for pos in (5, 100, len(proof) - 40, len(proof) - 1):
+            bad = bytearray(proof); bad[pos] ^= 0x01
+            want = O.verify(ogens, vstate or state, vcirc or oc, coms, bytes(bad), flags=flags)
+            got = ctx.verify_flat(vinst, vstate or state, coms, bytes(bad), flags=flags)
+            assert want != 0 and got == want, (pos, want, got)
+        assert ctx.verify_flat(vinst, vstate or state, coms, proof[:-1], flags=flags) == 2
+        if coms:
+            badc = bytearray(coms); badc[0] ^= 2
+            assert ctx.verify_flat(vinst, vstate or state, bytes(badc), proof, flags=flags) in (2, 3)
         proofs.append(proof)
     res.free()
     return proofs
@@ -343,16 +356,21 @@ def test_cfg4_full_merkle_2_20_roundtrip(ctx):
     vi = v.instance()
     assert tv.state == state and v.get_num_vars() == inst.n
     vc = to_oracle(vi)
-    assert O.verify(og, tv.state, vc, b"".join(a.commitments), proof) == 0
+    vstate = tv.state                                                    # Verifier::verify consumes the transcript: keep the pre-verify state
+    assert O.verify(og, vstate, vc, b"".join(a.commitments), proof) == 0
+    assert v.is_valid(proof, ctx, a.gens_capacity)                      # GPU verifier on the 2^20 circuit
     bad = bytearray(proof); bad[700] ^= 0x40
-    assert O.verify(og, tv.state, vc, b"".join(a.commitments), bytes(bad)) != 0
+    tv2 = bpg.Transcript(b"MerkleTree"); v2 = bpg.Verifier(tv2); a.replay(v2)
+    assert not v2.is_valid(bytes(bad), ctx, a.gens_capacity)
+    assert O.verify(og, vstate, vc, b"".join(a.commitments), bytes(bad)) != 0
     # determinism: same seed -> same bytes; different seed -> different proof that still verifies
     res = ctx.upload(inst)
     p2, _ = res.prove(state, inst.v_blinding, bytes(range(32)))
     p3, _ = res.prove(state, inst.v_blinding, bytes(32))
     res.free()
     assert p2 == proof and p3 != proof
-    assert O.verify(og, tv.state, vc, b"".join(a.commitments), p3) == 0
+    assert O.verify(og, vstate, vc, b"".join(a.commitments), p3) == 0
+    assert ctx.verify_flat(vi, vstate, b"".join(a.commitments), p3) == 0
 
 
 def test_skewed_witness_distributions(ctx):
