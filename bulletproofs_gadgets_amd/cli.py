@@ -1,0 +1,249 @@
+"""File driver for the reference's CLI formats, BOUND / HASH / MERKLE subset.
+
+    python -m bulletproofs_gadgets_amd.cli prover   NAME      reads NAME.gadgets/.inst/.wtns, writes NAME.coms/.proof
+    python -m bulletproofs_gadgets_amd.cli verifier NAME      reads NAME.gadgets/.inst/.coms/.proof, prints true/false
+
+Mirrors reference src/bin/prover.rs:47-100 and src/bin/verifier.rs:46-101 for the three gadget kinds of the benchmark
+configurations: the transcript label is the NAME argument (prover.rs:49-52); witnesses are committed in .wtns order and
+written as "C{id}-{k} = 0x.." (assignment_parser.rs:152-169,213-220); derived commitments as "D{line}-{sub}-{k}";
+MERKLE hashes every W leaf through hash_witness (prover.rs:160-190) and every I leaf through mimc_hash (prover.rs:192-200);
+generators: round_pow2(#multipliers) (prover.rs:43-45,92). The shadow ProverBuffer of the reference only exists to support OR
+blocks (not in this subset); recording and replaying its operations is the identity on multiplier / constraint order.
+EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN / OR lines raise NotImplementedError (row f3).
+"""
+import hashlib
+import os
+import re
+import sys
+
+from . import (BoundsCheck, BulletproofGens, Context, MerkleTree256, MimcHash256, Prover, Transcript, Verifier, be_to_scalar,
+               commit, commit_single, mimc_hash, scalar_to_be, L)
+
+_VAR = re.compile(r"^\s*([A-Za-z][0-9]+(?:-[0-9]+){0,2})\s*=\s*0[xX]([0-9a-fA-F]+)\s*$")
+
+
+def _read_vars(path):
+    out = []
+    with open(path) as f:
+        for line in f:
+            if not line.strip():
+                continue
+            m = _VAR.match(line)
+            if not m:
+                raise ValueError("cannot parse %r in %s" % (line, path))
+            out.append((m.group(1), bytes.fromhex(m.group(2))))
+    return out
+
+
+def round_pow2(n):
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+class _Blindings:
+    """Scalar::random(&mut thread_rng()) stand-in: os.urandom, or a SHAKE256 stream when a seed is given (tests)."""
+    def __init__(self, seed=None):
+        self.seed, self.ctr = seed, 0
+
+    def next(self):
+        if self.seed is None:
+            raw = os.urandom(64)
+        else:
+            raw = hashlib.shake_256(self.seed + self.ctr.to_bytes(8, "little")).digest(64)
+            self.ctr += 1
+        return (int.from_bytes(raw, "little") % L).to_bytes(32, "little")
+
+    def take(self, k):
+        return [self.next() for _ in range(k)]
+
+
+def parse_tree(text):
+    """Tree syntax of gadget_grammar.lalrpop:54-79 -> (instance names, witness names, pattern string), left to right."""
+    toks = re.findall(r"\(|\)|[WI][0-9]+", text)
+    pos = 0
+    inst, wit = [], []
+
+    def node():
+        nonlocal pos
+        t = toks[pos]; pos += 1
+        if t == "(":
+            l = node(); r = node()
+            if pos >= len(toks) or toks[pos] != ")":
+                raise ValueError("malformed tree")
+            pos += 1
+            return "(%s %s)" % (l, r)
+        if t[0] == "W":
+            wit.append(t); return "W"
+        if t[0] == "I":
+            inst.append(t); return "I"
+        raise ValueError("malformed tree")
+    pat = node()
+    if pos != len(toks) or not pat.startswith("("):
+        raise ValueError("malformed tree")
+    return inst, wit, pat
+
+
+def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
+    ctx = ctx or Context(0)
+    rnd = _Blindings(seed)
+    transcript = Transcript(name.encode())
+    p = Prover(ctx, transcript)
+    instance = dict(_read_vars(name + ".inst"))
+    witness = {}
+    coms_lines = []
+    for wname, data in _read_vars(name + ".wtns"):                       # assignment_parser.rs:152-169
+        scalars, coms, vars_ = commit(p, data, rnd.take((len(data) + 31) // 32 or 1))
+        witness[wname] = (scalars, coms, vars_, data)
+        for k, c in enumerate(coms):
+            coms_lines.append("C%s-%d = 0x%s\n" % (wname[1:], k, c.hex()))
+
+    def derived_lines(coms, index, sub):                                  # assignment_parser.rs:198-211
+        for k, c in enumerate(coms):
+            coms_lines.append("D%d-%d-%d = 0x%s\n" % (index, sub, k, c.hex()))
+
+    def single(wname):
+        w = witness[wname]
+        assert len(w[0]) == 1, "witness var %s is longer than 32 bytes" % wname
+        return w
+
+    def lc_of(token):
+        if token[0] == "W":
+            return single(token)[2][0]
+        data = instance[token]
+        assert len(data) <= 32, "instance var %s is longer than 32 bytes" % token
+        return be_to_scalar(data)
+
+    with open(name + ".gadgets") as f:
+        lines = [l.rstrip("\n") for l in f]
+    for index, line in enumerate(lines):
+        parts = line.split()
+        if not parts:
+            continue
+        op = parts[0]
+        if op == "BOUND":                                                 # prover.rs:253-276
+            w = single(parts[1])
+            lo, hi = instance[parts[2]], instance[parts[3]]
+            g = BoundsCheck(lo, hi)
+            dcoms, derived = g.setup(p, w[0], rnd.take(2))
+            g.prove(p, w[2], derived)
+            derived_lines(dcoms, index, 0)
+        elif op == "HASH":                                                # prover.rs:278-305
+            g = MimcHash256(lc_of(parts[1]))
+            w = witness[parts[2]]
+            dcoms, derived = g.setup(p, w[0], rnd.take(2))
+            g.prove(p, w[2], derived)
+            derived_lines(dcoms, index, 0)
+        elif op == "MERKLE":                                              # prover.rs:307-339
+            root = lc_of(parts[1])
+            inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
+            inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
+            wit_lcs = []
+            for sub, wn in enumerate(wit_names):                          # hash_witness, prover.rs:160-190
+                w = witness[wn]
+                image = mimc_hash(w[3])
+                _, image_com, image_var = commit_single(p, scalar_to_be(image), rnd.next())
+                hg = MimcHash256(image_var)
+                dcoms, derived = hg.setup(p, w[0], rnd.take(2))
+                hg.prove(p, w[2], derived)
+                derived_lines([image_com] + dcoms, index, sub)
+                wit_lcs.append(image_var)
+            MerkleTree256(root, inst_lcs, wit_lcs, pattern).prove(p, [], [])
+        else:
+            raise NotImplementedError("gadget %s is outside the BOUND/HASH/MERKLE subset (SURVEY.md 8f row f3)" % op)
+    if not quiet:
+        print(p.num_constraints())                                        # prover.rs:89
+    cap = round_pow2(p.get_num_multiplications())
+    proof = p.prove(BulletproofGens(ctx, cap), rng_seed if rng_seed is not None else os.urandom(32), flags)
+    with open(name + ".coms", "w") as f:
+        f.writelines(coms_lines)
+    with open(name + ".proof", "wb") as f:
+        f.write(proof)
+    return p, proof
+
+
+def assemble_verifier(name):
+    """Verifier-side replay (verifier.rs:46-90) up to, not including, verify(). Returns (Verifier, transcript)."""
+    transcript = Transcript(name.encode())
+    v = Verifier(transcript)
+    instance = dict(_read_vars(name + ".inst"))
+    commitments = {}
+    for cname, data in _read_vars(name + ".coms"):                        # parse_coms: every line, file order
+        if len(data) != 32:
+            raise ValueError("commitment %s is not 32 bytes" % cname)
+        commitments[cname] = v.commit(data)
+
+    def all_commitments(wname):
+        out, k = [], 0
+        while "C%s-%d" % (wname[1:], k) in commitments:
+            out.append(commitments["C%s-%d" % (wname[1:], k)]); k += 1
+        if not out:
+            raise KeyError("missing commitment C%s-0" % wname[1:])
+        return out
+
+    def lc_of(token):
+        if token[0] == "W":
+            return commitments["C%s-0" % token[1:]]
+        return be_to_scalar(instance[token])
+
+    def derived(index, sub, upto):
+        out = []
+        for k in range(upto):
+            key = "D%d-%d-%d" % (index, sub, k)
+            if key not in commitments:
+                break
+            out.append(commitments[key])
+        return out
+
+    with open(name + ".gadgets") as f:
+        lines = [l.rstrip("\n") for l in f]
+    for index, line in enumerate(lines):
+        parts = line.split()
+        if not parts:
+            continue
+        op = parts[0]
+        if op == "BOUND":                                                 # verifier.rs:188-205
+            BoundsCheck(instance[parts[2]], instance[parts[3]]).verify(v, [commitments["C%s-0" % parts[1][1:]]], derived(index, 0, 2))
+        elif op == "HASH":                                                # verifier.rs:207-230
+            MimcHash256(lc_of(parts[1])).verify(v, all_commitments(parts[2]), derived(index, 0, 2))
+        elif op == "MERKLE":                                              # verifier.rs:232-260, hash_witness :426-444
+            root = lc_of(parts[1])
+            inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
+            inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
+            wit_lcs = []
+            for sub, wn in enumerate(wit_names):
+                d = derived(index, sub, 3)
+                image = d[0]
+                MimcHash256(image).verify(v, all_commitments(wn), d[1:])
+                wit_lcs.append(image)
+            MerkleTree256(root, inst_lcs, wit_lcs, pattern).verify(v, [], [])
+        else:
+            raise NotImplementedError("gadget %s is outside the BOUND/HASH/MERKLE subset (SURVEY.md 8f row f3)" % op)
+    return v, transcript
+
+
+def verifier(name, ctx=None, flags=0, quiet=False):
+    ctx = ctx or Context(0)
+    v, _ = assemble_verifier(name)
+    with open(name + ".proof", "rb") as f:
+        proof = f.read()
+    ok = v.is_valid(proof, ctx, round_pow2(v.get_num_vars()), os.urandom(32), flags)
+    if not quiet:
+        print("true" if ok else "false")                                  # verifier.rs:91-100
+    return ok
+
+
+def main(argv=None):
+    argv = argv if argv is not None else sys.argv[1:]
+    if len(argv) != 2 or argv[0] not in ("prover", "verifier"):
+        print(__doc__)
+        return 2
+    if argv[0] == "prover":
+        prover(argv[1])
+        return 0
+    return 0 if verifier(argv[1]) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
