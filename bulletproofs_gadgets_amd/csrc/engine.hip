@@ -78,12 +78,13 @@ uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; re
 struct DeviceCircuit {
     uint64_t n = 0, m = 0, q = 0, ncols = 0, nnz = 0;
     bool has_witness = false;
+    uint64_t const_begin = 0;      // first entry of the constant-terms column (the last one)
     DevBuf aL, aR, aO, col_ptr, ent_row, ent_coef, coef;
 };
 
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
-    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
+    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_digits_count) X(k_msm_digits_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul)
 enum KernelId {
@@ -400,7 +401,7 @@ DeviceCircuit *Engine::upload(const FlatCircuit &c) {
             uint64_t pos = fill[col]++; ent_row[pos] = (uint32_t)r; ent_coef[pos] = c.term_coef[k];
         }
     DeviceCircuit *d = new DeviceCircuit();
-    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept; d->has_witness = has_witness;
+    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept; d->has_witness = has_witness; d->const_begin = col_ptr[ncols - 1];
     try {
         d->aL.ensure((n ? n : 1) * sizeof(scm)); d->aR.ensure((n ? n : 1) * sizeof(scm)); d->aO.ensure((n ? n : 1) * sizeof(scm));
         d->col_ptr.ensure((ncols + 1) * 8); d->ent_row.ensure(ent_row.size() * 4); d->ent_coef.ensure(ent_coef.size() * 4);
@@ -529,9 +530,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     exp_table(y, I.ypow.as<scm>(), N);
     exp_table(yinv, I.yinvpow.as<scm>(), N);
     exp_table(z, I.zpow.as<scm>(), q + 1);
-    if (c->ncols)
-        BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
-                           c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)c->ncols, (uint32_t)(3 * n));
+    if (c->ncols > 1)      // every column but the last (constant terms: verifier only)
+        BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
+                           c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
     scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;
     const uint32_t pblocks = n ? std::min<uint32_t>(cdiv(n, 256), 1024) : 1;
     I.red_partial.ensure((size_t)pblocks * 6 * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
@@ -619,28 +620,31 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         if (h > 1 || true) {
             // generator fold: Gst'[i] = Gst[i] + sG * Gst[h+i],  Hst'[i] = Hst[i] + sH * Hst[h+i]
             const Scalar sGA = u * u, sHA = uinv * uinv * yinv_pow2[ceil_log2(h)];
-            FoldNaf *hn = reinterpret_cast<FoldNaf *>(I.h_small.as<uint8_t>() + 4096);
-            hn->top[0] = naf256(sGA, hn->d[0]);
-            hn->top[2] = naf256(sHA, hn->d[2]);
-            if (first) { hn->top[1] = naf256(sGA * u_ch, hn->d[1]); hn->top[3] = naf256(sHA * u_ch, hn->d[3]); }
-            else { std::memcpy(hn->d[1], hn->d[0], 256); hn->top[1] = hn->top[0]; std::memcpy(hn->d[3], hn->d[2], 256); hn->top[3] = hn->top[2]; }
-            HIPCHK(hipMemcpyAsync(I.naf.p, hn, sizeof(FoldNaf), hipMemcpyHostToDevice, st));
+            int8_t dg[4][256]; int32_t tops[4];
+            tops[0] = naf256(sGA, dg[0]);
+            tops[2] = naf256(sHA, dg[2]);
+            if (first) { tops[1] = naf256(sGA * u_ch, dg[1]); tops[3] = naf256(sHA * u_ch, dg[3]); }
+            else { std::memcpy(dg[1], dg[0], 256); tops[1] = tops[0]; std::memcpy(dg[3], dg[2], 256); tops[3] = tops[2]; }
+            FoldNaf fn; std::memset(&fn, 0, sizeof fn);
+            for (int cls = 0; cls < 4; cls++) {
+                fn.top[cls] = tops[cls];
+                for (int k = 0; k < 256; k++) { if (dg[cls][k]) fn.nz[cls][k >> 5] |= 1u << (k & 31); if (dg[cls][k] < 0) fn.neg[cls][k >> 5] |= 1u << (k & 31); }
+            }
             const uint32_t split = first ? (uint32_t)(n - h) : (uint32_t)h;
             ge_niels *dst = (round & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<FoldNaf>(), (uint32_t)h, split);
+            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), fn, (uint32_t)h, split);
             {   // bookkeeping for the roofline: 4h points read + 2h written at 32 B (information content) resp. 96/128 B (device formats);
                 // field multiplications: 8 per doubling, 7 per mixed addition
                 double fm = 0;
                 for (int cls = 0; cls < 4; cls++) {
-                    int adds = 0; for (int k = 0; k <= hn->top[cls]; k++) adds += hn->d[cls][k] != 0;
+                    int adds = 0; for (int k = 0; k <= tops[cls]; k++) adds += dg[cls][k] != 0;
                     const double lanes = (cls & 1) ? (double)(h - split) : (double)split;
-                    fm += lanes * (8.0 * (hn->top[cls] + 1) + 7.0 * adds + 7.0);
+                    fm += lanes * (8.0 * (tops[cls] + 1) + 7.0 * adds + 7.0);
                 }
                 I.prof_note(KID_k_fold_points, 32.0 * 6 * h, 96.0 * 4 * h + 128.0 * 2 * h, fm);
             }
             BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * h, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, (uint32_t)(2 * h));
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));      // hn (pinned) is rewritten next round
             Gst = dst; Hst = dst + h;
         }
         Gamma = uinv * Gamma; Eta = u * Eta;
@@ -722,6 +726,7 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
         for (uint32_t k = 0; k < lgN; k++) { std::memcpy(&hpts[o], pLR + 64 * k, 32); o += 32; }
         for (uint32_t k = 0; k < lgN; k++) { std::memcpy(&hpts[o], pLR + 64 * k + 32, 32); o += 32; }
     }
+    I.red_partial.ensure((size_t)4096 * sizeof(scm)); I.red_out.ensure(16 * sizeof(scm));      // [0,1024): delta partials, [1024,1536): w_c partials
     I.vfy_in.ensure((size_t)npts * 32); I.vfy_pts.ensure((size_t)npts * sizeof(ge_niels)); I.vfy_ok.ensure((size_t)npts * 4);
     I.vfy_sc.ensure((size_t)(npts + 2) * sizeof(scm)); I.vfy_ch.ensure(sizeof(IpaChallenges));
     HIPCHK(hipMemcpyAsync(I.vfy_in.p, hpts.data(), hpts.size(), hipMemcpyHostToDevice, st));
@@ -733,9 +738,17 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
     };
     exp_table(yinv, I.yinvpow.as<scm>(), N);
     exp_table(z, I.zpow.as<scm>(), q + 1);
-    BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(),
-               c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)c->ncols, (uint32_t)(3 * n));
+    if (c->ncols > 1)
+        BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(),
+                   c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
     scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;      // wV[m] = w_c
+    {   // w_c: grid-wide reduction over the constant-term entries
+        const uint64_t e0 = c->const_begin, e1 = c->nnz;
+        const uint32_t cb = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(e1 - e0, 256), 512));
+        BPG_LAUNCH(I, k_flatten_const, dim3(cb), dim3(256), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), e0, e1,
+                   I.red_partial.as<scm>() + 1024);
+        BPG_LAUNCH(I, k_reduce_partials, dim3(1), dim3(256), I.red_partial.as<scm>() + 1024, cb, 1u, wV + m);
+    }
     {
         I.h_small.ensure(1 << 16);
         IpaChallenges *hc = reinterpret_cast<IpaChallenges *>(I.h_small.as<uint8_t>() + 8192);
@@ -746,7 +759,6 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
     scm *svec = I.ypow.as<scm>(), *gsc = I.lv.as<scm>(), *hsc = I.rv.as<scm>();
     BPG_LAUNCH(I, k_ipa_s, dim3(cdiv(N, 256)), dim3(256), I.vfy_ch.as<IpaChallenges>(), svec, lgN, (uint32_t)N);
     const uint32_t blocks = std::min<uint32_t>(cdiv(N, 256), 1024);
-    I.red_partial.ensure((size_t)blocks * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
     BPG_LAUNCH(I, k_verify_scalars, dim3(blocks), dim3(256), wL, wR, wO, I.yinvpow.as<scm>(), svec, to_scm(x), to_scm(ipa), to_scm(ipb), to_scm(u_ch),
                gsc, hsc, I.red_partial.as<scm>(), (uint32_t)n, (uint32_t)N);
     BPG_LAUNCH(I, k_reduce_partials, dim3(1), dim3(256), I.red_partial.as<scm>(), blocks, 1u, I.red_out.as<scm>());

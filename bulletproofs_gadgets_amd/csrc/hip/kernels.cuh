@@ -215,6 +215,19 @@ __global__ void __launch_bounds__(256) k_flatten(const uint64_t *__restrict__ co
     w[c] = (c >= first_neg_col) ? sc_neg(acc) : acc;
 }
 
+// w_c = - sum over the constant terms (Variable::One) of coef * z^(row+1): the one column of the constraint matrix that holds
+// O(q) entries, so it gets a grid-wide reduction instead of a k_flatten thread (verifier only; the prover never needs it)
+__global__ void __launch_bounds__(256) k_flatten_const(const uint32_t *__restrict__ ent_row, const uint32_t *__restrict__ ent_coef,
+                                                       const scm *__restrict__ coef, const scm *__restrict__ zpow, uint64_t e0, uint64_t e1,
+                                                       scm *__restrict__ partial) {
+    __shared__ scm lds[256];
+    scm acc = sc_zero();
+    for (uint64_t e = e0 + blockIdx.x * blockDim.x + threadIdx.x; e < e1; e += (uint64_t)gridDim.x * blockDim.x)
+        acc = sc_add(acc, sc_mont_mul(coef[ent_coef[e]], zpow[ent_row[e] + 1]));
+    scm r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) partial[blockIdx.x] = sc_neg(r);
+}
+
 // t1..t6 partial sums of <l(X), r(X)>:  l1 = aL + y^-i wR, l2 = aO, l3 = sL ; r0 = wO - y^i, r1 = y^i aR + wL, r3 = y^i sR
 __global__ void __launch_bounds__(256) k_poly_t(const scm *__restrict__ aL, const scm *__restrict__ aR, const scm *__restrict__ aO,
                                                 const scm *__restrict__ sL, const scm *__restrict__ sR,
@@ -306,25 +319,39 @@ __global__ void __launch_bounds__(256) k_ipa_fold_scalars(scm *__restrict__ a, s
 // Generator fold with a wave-uniform scalar: out[i] = P_i + s * Q_i, P_i = tab[i], Q_i = tab[h + i].
 // naf[k] in {-1,0,1} is the non-adjacent form of s (shared by every lane, so the add/skip branch never diverges).
 // Threads [0,h) fold G with nafG{A,B}, threads [h,2h) fold H with nafH{A,B}; class B applies to i >= split (first round only).
-struct FoldNaf { int8_t d[4][256]; int32_t top[4]; };
+// The NAF travels in the kernel arguments (SGPRs): nz/neg bit k = digit k non-zero / negative. A wave whose lanes all
+// belong to one class takes the scalar path (s_cbranch on the digit, the addition is skipped, not masked); the at most
+// three waves per launch that straddle a class boundary take the per-lane path.
+struct FoldNaf { uint32_t nz[4][8]; uint32_t neg[4][8]; int32_t top[4]; };
 __global__ void __launch_bounds__(256) k_fold_points(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H,
-                                                     ge_ext *__restrict__ out /* 2h */, const FoldNaf *__restrict__ naf,
-                                                     uint32_t h, uint32_t split) {
+                                                     ge_ext *__restrict__ out /* 2h */, const FoldNaf naf, uint32_t h, uint32_t split) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * h) return;
+    const bool live = t < 2 * h;
+    if (!live) t = 2 * h - 1;                               // keep whole waves converged; the store is guarded
     const bool isH = t >= h;
     const uint32_t i = isH ? t - h : t;
     const ge_niels *tab = isH ? H : G;
     const int cls = (isH ? 2 : 0) + (i >= split ? 1 : 0);
     const ge_niels Q = tab[h + i];
-    const int8_t *d = naf->d[cls];
     ge_ext acc = ge_identity();
-    for (int k = naf->top[cls]; k >= 0; k--) {
-        acc = ge_dbl(acc);
-        int8_t dk = d[k];
-        if (dk != 0) acc = ge_madd_signed(acc, Q, dk < 0);
+    const int cls0 = __builtin_amdgcn_readfirstlane(cls);
+    if (__ballot(cls != cls0) == 0ull) {
+        for (int k = naf.top[cls0]; k >= 0; k--) {
+            acc = ge_dbl(acc);
+            const uint32_t nz = (naf.nz[cls0][k >> 5] >> (k & 31)) & 1u;         // scalar
+            if (nz) acc = ge_madd_signed(acc, Q, (naf.neg[cls0][k >> 5] >> (k & 31)) & 1u);
+        }
+    } else {
+        int top = naf.top[0];
+        for (int c = 1; c < 4; c++) top = naf.top[c] > top ? naf.top[c] : top;
+        for (int k = top; k >= 0; k--) {
+            acc = ge_dbl(acc);                              // doubling the identity above a class's top digit is harmless
+            uint32_t nz = 0, ng = 0;
+            for (int c = 0; c < 4; c++) if (c == cls) { nz = (naf.nz[c][k >> 5] >> (k & 31)) & 1u; ng = (naf.neg[c][k >> 5] >> (k & 31)) & 1u; }
+            if (nz) acc = ge_madd_signed(acc, Q, ng);
+        }
     }
-    out[t] = ge_madd(acc, tab[i]);
+    if (live) out[t] = ge_madd(acc, tab[i]);
 }
 
 // ------------------------------------------------------------------------------------------------ verifier
