@@ -56,37 +56,28 @@ __device__ __forceinline__ void fe_mac(uint64_t &lo, uint32_t &hi, uint32_t a, u
     uint64_t c;
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(lo), "+v"(hi), "=&s"(c) : "v"(a), "v"(b));
 }
-// r = t[0..7] + 38 * t[8..15] (mod p, weakly reduced): three carry chains
+// 64-bit product h * 38 in ONE instruction (both halves), and a * a likewise
+__device__ __forceinline__ uint64_t fe_mul38(uint32_t h) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, 38, 0" : "=v"(p), "=s"(c) : "v"(h)); return p; }
+__device__ __forceinline__ uint64_t fe_sqr32(uint32_t a) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, %2, 0" : "=v"(p), "=s"(c) : "v"(a)); return p; }
+// r = t[0..7] + 38 * t[8..15] (mod p, weakly reduced): 8 MADs and three v_addc chains (__builtin_addc lowers to v_addc_co_u32)
 __device__ __forceinline__ fe fe_fold512_dev(const uint32_t t[16]) {
-    fe r; uint32_t x, top;
-    asm("v_mul_lo_u32 %8, %18, 38\n\tv_add_co_u32_e32 %0, vcc, %10, %8\n\t"
-        "v_mul_lo_u32 %8, %19, 38\n\tv_addc_co_u32_e32 %1, vcc, %11, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %20, 38\n\tv_addc_co_u32_e32 %2, vcc, %12, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %21, 38\n\tv_addc_co_u32_e32 %3, vcc, %13, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %22, 38\n\tv_addc_co_u32_e32 %4, vcc, %14, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %23, 38\n\tv_addc_co_u32_e32 %5, vcc, %15, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %24, 38\n\tv_addc_co_u32_e32 %6, vcc, %16, %8, vcc\n\t"
-        "v_mul_lo_u32 %8, %25, 38\n\tv_addc_co_u32_e32 %7, vcc, %17, %8, vcc\n\t"
-        "v_addc_co_u32_e64 %9, vcc, 0, 0, vcc\n\t"
-        "v_mul_hi_u32 %8, %18, 38\n\tv_add_co_u32_e32 %1, vcc, %1, %8\n\t"
-        "v_mul_hi_u32 %8, %19, 38\n\tv_addc_co_u32_e32 %2, vcc, %2, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %20, 38\n\tv_addc_co_u32_e32 %3, vcc, %3, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %21, 38\n\tv_addc_co_u32_e32 %4, vcc, %4, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %22, 38\n\tv_addc_co_u32_e32 %5, vcc, %5, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %23, 38\n\tv_addc_co_u32_e32 %6, vcc, %6, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %24, 38\n\tv_addc_co_u32_e32 %7, vcc, %7, %8, vcc\n\t"
-        "v_mul_hi_u32 %8, %25, 38\n\tv_addc_co_u32_e32 %9, vcc, %9, %8, vcc\n\t"
-        "v_mul_u32_u24_e32 %9, 38, %9\n\t"
-        "v_add_co_u32_e32 %0, vcc, %0, %9\n\t"
-        "v_addc_co_u32_e32 %1, vcc, 0, %1, vcc\n\tv_addc_co_u32_e32 %2, vcc, 0, %2, vcc\n\t"
-        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
-        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\tv_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
-        "v_addc_co_u32_e32 %7, vcc, 0, %7, vcc\n\t"
-        "v_cndmask_b32_e64 %8, 0, 38, vcc\n\t"
-        "v_add_u32_e32 %0, %0, %8"
-        : "=&v"(r.v[0]), "=&v"(r.v[1]), "=&v"(r.v[2]), "=&v"(r.v[3]), "=&v"(r.v[4]), "=&v"(r.v[5]), "=&v"(r.v[6]), "=&v"(r.v[7]), "=&v"(x), "=&v"(top)
-        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]),
-          "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]), "v"(t[14]), "v"(t[15]) : "vcc");
+    uint64_t p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = fe_mul38(t[8 + i]);
+    fe r; uint32_t c = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { r.v[i] = __builtin_addc(t[i], (uint32_t)p[i], c, &co); c = co; }
+    uint32_t top = c;
+    c = 0;
+#pragma unroll
+    for (int i = 1; i < 8; i++) { r.v[i] = __builtin_addc(r.v[i], (uint32_t)(p[i - 1] >> 32), c, &co); c = co; }
+    top += (uint32_t)(p[7] >> 32) + c;                       // <= 1 + 37 + 1
+    const uint32_t f = top * 38u;
+    c = 0;
+    r.v[0] = __builtin_addc(r.v[0], f, 0u, &co); c = co;
+#pragma unroll
+    for (int i = 1; i < 8; i++) { r.v[i] = __builtin_addc(r.v[i], 0u, c, &co); c = co; }
+    r.v[0] += 38u * c;                                       // a second wrap leaves a tiny value: no further carry
     return r;
 }
 __device__ __forceinline__ fe fe_mul(const fe &a, const fe &b) {
@@ -108,25 +99,33 @@ __device__ __forceinline__ fe fe_mul(const fe &a, const fe &b) {
     return fe_fold512_dev(t);
 }
 __device__ __forceinline__ fe fe_sq(const fe &a) {
-    // column k: 2 * sum_{i<j, i+j=k} a_i a_j + (k even ? a_{k/2}^2 : 0) + carry of column k-1
-    uint32_t t[16];
-    uint64_t clo = 0;                              // carry from the previous column (< 2^36)
+    // a^2 = 2 * U + D with U = sum_{i<j} a_i a_j 2^(32(i+j)) (28 products, column scanning as in fe_mul),
+    // doubled as one 512-bit shift (v_alignbit per limb), and D = sum a_i^2 2^(64 i) added with one carry chain.
+    uint32_t u[16];
+    u[0] = 0;
+    uint64_t lo = 0; uint32_t hi = 0;
 #pragma unroll
-    for (int k = 0; k < 15; k++) {
+    for (int k = 1; k < 14; k++) {
         const int i0 = (k > 7 ? k - 7 : 0);
-        uint64_t lo = 0; uint32_t hi = 0;
+        hi = 0;
 #pragma unroll
         for (int i = i0; 2 * i < k; i++) {
-            if (i == i0) fe_mac_first(lo, a.v[i], a.v[k - i]);
-            else if (i == i0 + 1) fe_mac_second(lo, hi, a.v[i], a.v[k - i]);
+            if (k == 1) fe_mac_first(lo, a.v[i], a.v[k - i]);
+            else if (i == i0) fe_mac_second(lo, hi, a.v[i], a.v[k - i]);
             else fe_mac(lo, hi, a.v[i], a.v[k - i]);
         }
-        hi = (hi << 1) | (uint32_t)(lo >> 63); lo <<= 1;          // double the off-diagonal sum
-        if ((k & 1) == 0) fe_mac(lo, hi, a.v[k / 2], a.v[k / 2]);
-        uint64_t s = lo + clo; hi += (s < lo ? 1u : 0u); lo = s;
-        t[k] = (uint32_t)lo; clo = (lo >> 32) | ((uint64_t)hi << 32);
+        u[k] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
     }
-    t[15] = (uint32_t)clo;
+    u[14] = (uint32_t)lo; u[15] = (uint32_t)(lo >> 32);
+    uint32_t t[16], c = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const uint64_t d = fe_sqr32(a.v[i]);
+        const uint32_t e0 = (2 * i == 0) ? 0u : __builtin_amdgcn_alignbit(u[2 * i], u[2 * i - 1], 31);     // limb 2i of 2U
+        const uint32_t e1 = __builtin_amdgcn_alignbit(u[2 * i + 1], u[2 * i], 31);                        // limb 2i+1 of 2U
+        t[2 * i] = __builtin_addc(e0, (uint32_t)d, c, &co); c = co;
+        t[2 * i + 1] = __builtin_addc(e1, (uint32_t)(d >> 32), c, &co); c = co;
+    }
     return fe_fold512_dev(t);
 }
 __device__ __forceinline__ fe fe_add(const fe &a, const fe &b) {
