@@ -498,7 +498,7 @@ class Gadget:
 
     def setup(self, prover: Prover, witnesses, blindings):
         """Gadget::setup (src/gadget.rs:18-38) -> (commitments, [(scalar, Variable)])."""
-        cap = 8
+        cap = max(8, len(blindings), 2 * len(witnesses) + 2)
         n = C.c_uint64(cap)
         coms, dsc, dvars = _buf(32 * cap), _buf(32 * cap), (C.c_uint32 * cap)()
         _chk(lib().bpg_gadget_setup(self._h, prover._h, b"".join(witnesses), C.c_uint64(len(witnesses)), b"".join(blindings),
@@ -549,6 +549,47 @@ class MerkleTree256(Gadget):
         iv, wv = _lc_array(instance_vars), _lc_array(witness_vars)
         _chk(lib().bpg_merkle_tree256_new(C.byref(r), iv, C.c_uint64(len(instance_vars)), wv, C.c_uint64(len(witness_vars)),
                                           pattern.encode(), C.byref(h)))
+        super().__init__(h)
+
+
+class Equality(Gadget):
+    """Equality::new(right_hand) (src/equality/equality_gadget.rs:35-40)."""
+    def __init__(self, right_hand):
+        h = C.c_void_p()
+        arr = _lc_array(right_hand)
+        _chk(lib().bpg_equality_new(arr, C.c_uint64(len(right_hand)), C.byref(h)))
+        super().__init__(h)
+
+
+class Inequality(Gadget):
+    """Inequality::new(right_hand, right_hand_assignment) (src/inequality/inequality_gadget.rs:95-101)."""
+    def __init__(self, right_hand, right_hand_assignment=None):
+        h = C.c_void_p()
+        arr = _lc_array(right_hand)
+        ra = b"".join(right_hand_assignment) if right_hand_assignment is not None else None
+        if ra == b"":
+            ra = bytes(32)      # non-NULL marker for an empty assignment list
+        _chk(lib().bpg_inequality_new(arr, C.c_uint64(len(right_hand)), ra, C.byref(h)))
+        super().__init__(h)
+
+
+class LessThan(Gadget):
+    """LessThan::new(left, left_assignment, right, right_assignment) (src/less_than/less_than_gadget.rs:69-86)."""
+    def __init__(self, left_hand, left_hand_assignment, right_hand, right_hand_assignment):
+        h = C.c_void_p()
+        l, r = LinearCombination.of(left_hand)._c(), LinearCombination.of(right_hand)._c()
+        _chk(lib().bpg_less_than_new(C.byref(l), left_hand_assignment, C.byref(r), right_hand_assignment, C.byref(h)))
+        super().__init__(h)
+
+
+class SetMembership(Gadget):
+    """SetMembership::new(value, value_assignment, instance_vars, instance_vars_assignments) (set_membership_gadget.rs:64-77)."""
+    def __init__(self, value, value_assignment, instance_vars, instance_vars_assignments):
+        h = C.c_void_p()
+        v = LinearCombination.of(value)._c()
+        arr = _lc_array(instance_vars)
+        ia = b"".join(instance_vars_assignments) if instance_vars_assignments else None
+        _chk(lib().bpg_set_membership_new(C.byref(v), value_assignment, arr, C.c_uint64(len(instance_vars)), ia, C.byref(h)))
         super().__init__(h)
 
 

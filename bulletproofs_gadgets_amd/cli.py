@@ -9,15 +9,15 @@ written as "C{id}-{k} = 0x.." (assignment_parser.rs:152-169,213-220); derived co
 MERKLE hashes every W leaf through hash_witness (prover.rs:160-190) and every I leaf through mimc_hash (prover.rs:192-200);
 generators: round_pow2(#multipliers) (prover.rs:43-45,92). The shadow ProverBuffer of the reference only exists to support OR
 blocks (not in this subset); recording and replaying its operations is the identity on multiplier / constraint order.
-EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN / OR lines raise NotImplementedError (row f3).
+EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN follow prover.rs:340-532 and verifier.rs:262-424 (row f3); OR blocks are not implemented.
 """
 import hashlib
 import os
 import re
 import sys
 
-from . import (BoundsCheck, BulletproofGens, Context, MerkleTree256, MimcHash256, Prover, Transcript, Verifier, be_to_scalar,
-               commit, commit_single, mimc_hash, scalar_to_be, L)
+from . import (BoundsCheck, BulletproofGens, Context, Equality, Inequality, LessThan, MerkleTree256, MimcHash256, Prover,
+               SetMembership, Transcript, Verifier, be_to_scalar, be_to_scalars, commit, commit_single, mimc_hash, scalar_to_be, L)
 
 _VAR = re.compile(r"^\s*([A-Za-z][0-9]+(?:-[0-9]+){0,2})\s*=\s*0[xX]([0-9a-fA-F]+)\s*$")
 
@@ -115,6 +115,16 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
         assert len(data) <= 32, "instance var %s is longer than 32 bytes" % token
         return be_to_scalar(data)
 
+    def hash_witness(wn, index, sub):                                     # prover.rs:160-190 -> (image scalar, image Variable)
+        w = witness[wn]
+        image = mimc_hash(w[3])
+        _, image_com, image_var = commit_single(p, scalar_to_be(image), rnd.next())
+        hg = MimcHash256(image_var)
+        dcoms, derived = hg.setup(p, w[0], rnd.take(2))
+        hg.prove(p, w[2], derived)
+        derived_lines([image_com] + dcoms, index, sub)
+        return image, image_var
+
     with open(name + ".gadgets") as f:
         lines = [l.rstrip("\n") for l in f]
     for index, line in enumerate(lines):
@@ -139,19 +149,70 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             root = lc_of(parts[1])
             inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
             inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
-            wit_lcs = []
-            for sub, wn in enumerate(wit_names):                          # hash_witness, prover.rs:160-190
-                w = witness[wn]
-                image = mimc_hash(w[3])
-                _, image_com, image_var = commit_single(p, scalar_to_be(image), rnd.next())
-                hg = MimcHash256(image_var)
-                dcoms, derived = hg.setup(p, w[0], rnd.take(2))
-                hg.prove(p, w[2], derived)
-                derived_lines([image_com] + dcoms, index, sub)
-                wit_lcs.append(image_var)
+            wit_lcs = [hash_witness(wn, index, sub)[1] for sub, wn in enumerate(wit_names)]
             MerkleTree256(root, inst_lcs, wit_lcs, pattern).prove(p, [], [])
+        elif op == "EQUALS":                                              # prover.rs:340-358 (grammar: W I | I W | W W)
+            left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
+            right_lcs = witness[right][2] if right[0] == "W" else be_to_scalars(instance[right])
+            Equality(right_lcs).prove(p, witness[left][2], [])
+        elif op == "LESS_THAN":                                           # prover.rs:360-382
+            l, r = single(parts[1]), single(parts[2])
+            g = LessThan(l[2][0], l[0][0], r[2][0], r[0][0])
+            dcoms, derived = g.setup(p, [], rnd.take(2))
+            g.prove(p, [], derived)
+            derived_lines(dcoms, index, 0)
+        elif op == "UNEQUAL":                                             # prover.rs:384-418
+            left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
+            lw = witness[left]
+            if right[0] == "W":
+                rs_, rl = witness[right][0], witness[right][2]
+            else:
+                rs_ = be_to_scalars(instance[right]); rl = rs_
+            g = Inequality(rl, rs_)
+            dcoms, derived = g.setup(p, lw[0], rnd.take(2 * len(lw[0]) + 1))
+            g.prove(p, lw[2], derived)
+            derived_lines(dcoms, index, 0)
+        elif op == "SET_MEMBER":                                          # prover.rs:420-532
+            member, elems = parts[1], parts[2:]
+            if member[0] == "W":
+                m_scalars, m_lcs = witness[member][0], witness[member][2]
+            else:
+                m_scalars = be_to_scalars(instance[member]); m_lcs = m_scalars
+            m_scalar, m_lc = m_scalars[0], m_lcs[0]
+            hashing = len(m_scalars) > 1
+            w_vars, w_scalars, i_lcs, i_scalars = [], [], [], []
+            if not hashing:
+                for e in elems:
+                    if e[0] == "W":
+                        if len(witness[e][2]) == 1:
+                            w_scalars.append(witness[e][0][0]); w_vars.append(witness[e][2][0])
+                        else:
+                            hashing = True
+                    else:
+                        sc_ = be_to_scalars(instance[e])
+                        if len(sc_) == 1:
+                            i_scalars.append(sc_[0]); i_lcs.append(sc_[0])
+                        else:
+                            hashing = True
+            if hashing:                                                   # elements longer than one scalar: compare MiMC images
+                sub = 1
+                if member[0] == "W":
+                    m_scalar, m_lc = hash_witness(member, index, sub); sub += 1
+                else:
+                    m_scalar = mimc_hash(instance[member]); m_lc = m_scalar
+                w_vars, w_scalars, i_lcs, i_scalars = [], [], [], []
+                for e in elems:
+                    if e[0] == "W":
+                        sc_, var = hash_witness(e, index, sub); sub += 1
+                        w_vars.append(var); w_scalars.append(sc_)
+                    else:
+                        h = mimc_hash(instance[e]); i_lcs.append(h); i_scalars.append(h)
+            g = SetMembership(m_lc, m_scalar, i_lcs, i_scalars)
+            dcoms, derived = g.setup(p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars)))
+            g.prove(p, w_vars, derived)
+            derived_lines(dcoms, index, 0)
         else:
-            raise NotImplementedError("gadget %s is outside the BOUND/HASH/MERKLE subset (SURVEY.md 8f row f3)" % op)
+            raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
     if not quiet:
         print(p.num_constraints())                                        # prover.rs:89
     cap = round_pow2(p.get_num_multiplications())
@@ -196,6 +257,11 @@ def assemble_verifier(name):
             out.append(commitments[key])
         return out
 
+    def hash_witness(wn, index, sub):                                     # verifier.rs:426-444 -> image Variable
+        d = derived(index, sub, 3)
+        MimcHash256(d[0]).verify(v, all_commitments(wn), d[1:])
+        return d[0]
+
     with open(name + ".gadgets") as f:
         lines = [l.rstrip("\n") for l in f]
     for index, line in enumerate(lines):
@@ -207,19 +273,61 @@ def assemble_verifier(name):
             BoundsCheck(instance[parts[2]], instance[parts[3]]).verify(v, [commitments["C%s-0" % parts[1][1:]]], derived(index, 0, 2))
         elif op == "HASH":                                                # verifier.rs:207-230
             MimcHash256(lc_of(parts[1])).verify(v, all_commitments(parts[2]), derived(index, 0, 2))
-        elif op == "MERKLE":                                              # verifier.rs:232-260, hash_witness :426-444
+        elif op == "MERKLE":                                              # verifier.rs:232-260
             root = lc_of(parts[1])
             inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
             inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
-            wit_lcs = []
-            for sub, wn in enumerate(wit_names):
-                d = derived(index, sub, 3)
-                image = d[0]
-                MimcHash256(image).verify(v, all_commitments(wn), d[1:])
-                wit_lcs.append(image)
+            wit_lcs = [hash_witness(wn, index, sub) for sub, wn in enumerate(wit_names)]
             MerkleTree256(root, inst_lcs, wit_lcs, pattern).verify(v, [], [])
+        elif op == "EQUALS":                                              # verifier.rs:262-280
+            left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
+            right_lcs = all_commitments(right) if right[0] == "W" else be_to_scalars(instance[right])
+            Equality(right_lcs).verify(v, all_commitments(left), [])
+        elif op == "LESS_THAN":                                           # verifier.rs:282-301
+            LessThan(commitments["C%s-0" % parts[1][1:]], None, commitments["C%s-0" % parts[2][1:]], None).verify(v, [], derived(index, 0, 2))
+        elif op == "UNEQUAL":                                             # verifier.rs:303-332
+            left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
+            lv = all_commitments(left)
+            right_lcs = all_commitments(right) if right[0] == "W" else be_to_scalars(instance[right])
+            d = [commitments["D%d-0-%d" % (index, k)] for k in range(2 * len(lv) + 1)]
+            Inequality(right_lcs, None).verify(v, lv, d)
+        elif op == "SET_MEMBER":                                          # verifier.rs:334-424
+            member, elems = parts[1], parts[2:]
+            m_lcs = all_commitments(member) if member[0] == "W" else be_to_scalars(instance[member])
+            m_lc = m_lcs[0]
+            hashing = False
+            w_vars, i_lcs = [], []
+            for e in elems:
+                if e[0] == "W":
+                    cw = all_commitments(e)
+                    if len(cw) == 1:
+                        w_vars.append(cw[0])
+                    else:
+                        hashing = True
+                else:
+                    sc_ = be_to_scalars(instance[e])
+                    if len(sc_) == 1:
+                        i_lcs.append(sc_[0])
+                    else:
+                        hashing = True
+            if len(m_lcs) > 1:
+                hashing = True
+            d = [commitments["D%d-0-%d" % (index, k)] for k in range(len(elems))]
+            if hashing:
+                sub = 1
+                if member[0] == "W":
+                    m_lc = hash_witness(member, index, sub); sub += 1
+                else:
+                    m_lc = mimc_hash(instance[member])
+                w_vars, i_lcs = [], []
+                for e in elems:
+                    if e[0] == "W":
+                        w_vars.append(hash_witness(e, index, sub)); sub += 1
+                    else:
+                        i_lcs.append(mimc_hash(instance[e]))
+            SetMembership(m_lc, None, i_lcs, None).verify(v, w_vars, d)
         else:
-            raise NotImplementedError("gadget %s is outside the BOUND/HASH/MERKLE subset (SURVEY.md 8f row f3)" % op)
+            raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
     return v, transcript
 
 

@@ -347,6 +347,28 @@ bpg_status bpg_merkle_tree256_new(const bpg_lc *root, const bpg_lc *inst, uint64
         *out = new bpg_gadget{std::unique_ptr<Gadget>(new MerkleTree256(lc_from(root), iv, wv, Pattern::parse(pattern)))};
     });
 }
+static std::vector<LinearCombination> lcs_from(const bpg_lc *a, uint64_t n) { std::vector<LinearCombination> o; for (uint64_t i = 0; i < n; i++) o.push_back(lc_from(&a[i])); return o; }
+static std::vector<Scalar> scalars_from(const uint8_t *p, uint64_t n) { std::vector<Scalar> o; if (p) for (uint64_t i = 0; i < n; i++) o.push_back(Scalar::from_bits(p + 32 * i)); return o; }
+bpg_status bpg_equality_new(const bpg_lc *right, uint64_t n, bpg_gadget **out) {
+    return guard([&] { REQUIRE(out && (n == 0 || right)); *out = new bpg_gadget{std::unique_ptr<Gadget>(new Equality(lcs_from(right, n)))}; });
+}
+bpg_status bpg_inequality_new(const bpg_lc *right, uint64_t n, const uint8_t *ra, bpg_gadget **out) {
+    return guard([&] { REQUIRE(out && (n == 0 || right)); *out = new bpg_gadget{std::unique_ptr<Gadget>(new Inequality(lcs_from(right, n), ra != nullptr, scalars_from(ra, n)))}; });
+}
+bpg_status bpg_less_than_new(const bpg_lc *left, const uint8_t *la, const bpg_lc *right, const uint8_t *ra, bpg_gadget **out) {
+    return guard([&] {
+        REQUIRE(out);
+        *out = new bpg_gadget{std::unique_ptr<Gadget>(new LessThan(lc_from(left), la ? OptScalar(Scalar::from_bits(la)) : OptScalar(), lc_from(right),
+                                                                   ra ? OptScalar(Scalar::from_bits(ra)) : OptScalar()))};
+    });
+}
+bpg_status bpg_set_membership_new(const bpg_lc *value, const uint8_t *va, const bpg_lc *inst, uint64_t n_inst, const uint8_t *ia, bpg_gadget **out) {
+    return guard([&] {
+        REQUIRE(out && (n_inst == 0 || inst));
+        *out = new bpg_gadget{std::unique_ptr<Gadget>(new SetMembership(lc_from(value), va ? OptScalar(Scalar::from_bits(va)) : OptScalar(), lcs_from(inst, n_inst),
+                                                                        ia != nullptr || n_inst == 0, scalars_from(ia, n_inst)))};
+    });
+}
 void bpg_gadget_free(bpg_gadget *g) { delete g; }
 
 bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *wit, uint64_t n_wit, const uint8_t *blind, uint64_t n_blind,

@@ -9,6 +9,10 @@
 //   MimcHash256        src/mimc_hash/mimc_hash_gadget.rs:7-150
 //   MerkleTree256      src/merkle_tree/merkle_tree_gadget.rs:14-113
 //   commitments        src/commitments.rs:8-47
+//   Equality           src/equality/equality_gadget.rs:5-40
+//   Inequality         src/inequality/inequality_gadget.rs:5-113
+//   LessThan           src/less_than/less_than_gadget.rs:6-86
+//   SetMembership      src/set_membership/set_membership_gadget.rs:5-132
 #pragma once
 #include <memory>
 #include "r1cs.hpp"
@@ -219,6 +223,122 @@ private:
     std::vector<LinearCombination> inst_, wit_;
     std::shared_ptr<Pattern> pattern_;
     MimcHash256 gadget_;
+};
+
+// ------------------------------------------------------------------------------------------ equality_gadget.rs
+// LEFT = RIGHT limb by limb; LEFT is a witness (variables), RIGHT witness or instance (linear combinations)
+class Equality : public Gadget {
+public:
+    explicit Equality(const std::vector<LinearCombination> &right_hand) : right_(right_hand) {}
+    std::vector<Scalar> preprocess(const std::vector<Scalar> &) const override { return {}; }
+    void assemble(ConstraintSystem &cs, const std::vector<Variable> &left, const Derived &) const override {
+        if (right_.size() != left.size()) { cs.constrain(LinearCombination(Scalar::one())); return; }      // unsatisfiable: 1 = 0
+        for (size_t i = 0; i < left.size(); i++) cs.constrain(right_[i] - LinearCombination(left[i]));
+    }
+private:
+    std::vector<LinearCombination> right_;
+};
+
+// ------------------------------------------------------------------------------------------ inequality_gadget.rs
+// LEFT != RIGHT: per limb delta = |left - right| (byte-wise comparison), delta * delta^-1 in {0,1}, and the sum of those has an inverse
+class Inequality : public Gadget {
+public:
+    Inequality(const std::vector<LinearCombination> &right_hand, bool has_assignment, const std::vector<Scalar> &right_assignment)
+        : right_(right_hand), has_(has_assignment), right_val_(right_assignment) {}
+    static bool compare(const Scalar &l, const Scalar &r) {                                 // :103-113, true when l >= r as 32-byte LE integers
+        for (int i = 31; i >= 0; i--) { uint8_t a = l.as_bytes()[i], b = r.as_bytes()[i]; if (a > b) return true; if (a < b) return false; }
+        return true;
+    }
+    std::vector<Scalar> preprocess(const std::vector<Scalar> &left) const override {        // :12-45
+        if (!has_) throw std::invalid_argument("missing right hand assignment");
+        std::vector<Scalar> d; Scalar sum;
+        for (size_t i = 0; i < left.size(); i++) {
+            const Scalar r = i < right_val_.size() ? right_val_[i] : Scalar::zero();
+            const Scalar delta = compare(left[i], r) ? left[i] - r : r - left[i];
+            d.push_back(delta);
+            if (delta == Scalar::zero()) d.push_back(Scalar::zero());
+            else { Scalar inv = delta.invert(); d.push_back(inv); sum = sum + delta * inv; }
+        }
+        d.push_back(sum.invert());
+        return d;
+    }
+    void assemble(ConstraintSystem &cs, const std::vector<Variable> &left, const Derived &d) const override {   // :47-92
+        if (right_.size() != left.size()) { cs.constrain(LinearCombination(Scalar::zero())); return; }
+        LinearCombination sum(Scalar::zero());
+        for (size_t i = 0; i < left.size(); i++) {
+            const LinearCombination l(left[i]), delta(d.at(2 * i).second), delta_inv(d.at(2 * i + 1).second);
+            MulVars z = cs.multiply((l - right_[i]) - delta, (right_[i] - l) - delta);      // (l - r - delta)(r - l - delta) = 0
+            cs.constrain(LinearCombination(z.o));
+            MulVars zo = cs.multiply(delta, delta_inv);
+            sum = sum + LinearCombination(zo.o);
+        }
+        MulVars one = cs.multiply(sum, LinearCombination(d.back().second));
+        cs.constrain(LinearCombination(Scalar::one()) - LinearCombination(one.o));
+    }
+private:
+    std::vector<LinearCombination> right_; bool has_; std::vector<Scalar> right_val_;
+};
+
+// ------------------------------------------------------------------------------------------ less_than_gadget.rs
+// LEFT < RIGHT with both in [0, 2^126): delta = right - left is range-checked and shown non-zero
+class LessThan : public Gadget {
+public:
+    LessThan(const LinearCombination &left, const OptScalar &left_assignment, const LinearCombination &right, const OptScalar &right_assignment)
+        : left_(left), right_(right), la_(left_assignment), ra_(right_assignment) {}
+    std::vector<Scalar> preprocess(const std::vector<Scalar> &) const override {            // :16-35
+        if (!la_.some || !ra_.some) throw std::invalid_argument("missing right hand assignment");
+        const Scalar delta = ra_.v - la_.v;
+        return {delta, delta == Scalar::zero() ? Scalar::zero() : delta.invert()};
+    }
+    void assemble(ConstraintSystem &cs, const std::vector<Variable> &, const Derived &d) const override {   // :37-66
+        const LinearCombination delta(d.at(0).second), delta_inv(d.at(1).second);
+        range_proof(cs, left_, 126, la_);
+        range_proof(cs, right_, 126, ra_);
+        range_proof(cs, delta, 126, d[0].first);
+        MulVars one = cs.multiply(delta, delta_inv);
+        cs.constrain(LinearCombination(Scalar::one()) - LinearCombination(one.o));
+        cs.constrain((right_ - left_) - delta);
+    }
+private:
+    LinearCombination left_, right_; OptScalar la_, ra_;
+};
+
+// ------------------------------------------------------------------------------------------ set_membership_gadget.rs
+// value is an element of (witness set || instance set): one-hot selector (derived), bits, sum 1, <selector, set> = value
+class SetMembership : public Gadget {
+public:
+    SetMembership(const LinearCombination &value, const OptScalar &value_assignment, const std::vector<LinearCombination> &instance_vars,
+                  bool has_instance_assignments, const std::vector<Scalar> &instance_assignments)
+        : value_(value), va_(value_assignment), inst_(instance_vars), has_(has_instance_assignments), inst_val_(instance_assignments) {}
+    std::vector<Scalar> preprocess(const std::vector<Scalar> &witnesses) const override {   // :13-34
+        if (!va_.some) throw std::invalid_argument("missing value assignment");
+        if (!has_) throw std::invalid_argument("missing instance vars assignments");
+        std::vector<Scalar> d;
+        for (auto &e : witnesses) d.push_back(e == va_.v ? Scalar::one() : Scalar::zero());
+        for (auto &e : inst_val_) d.push_back(e == va_.v ? Scalar::one() : Scalar::zero());
+        return d;
+    }
+    void assemble(ConstraintSystem &cs, const std::vector<Variable> &witnesses, const Derived &d) const override {   // :36-61
+        std::vector<LinearCombination> one_hot;
+        for (auto &b : d) {
+            LinearCombination bit(b.second);
+            MulVars z = cs.multiply(LinearCombination(Scalar::one()) - bit, bit);          // is_bit :98-110
+            cs.constrain(LinearCombination(z.o));
+            one_hot.push_back(bit);
+        }
+        LinearCombination sum(Scalar::zero());                                              // one_hot_vector :80-95
+        for (auto &b : one_hot) sum = sum + b;
+        cs.constrain(LinearCombination(Scalar::one()) - sum);
+        std::vector<LinearCombination> set;
+        for (auto &w : witnesses) set.push_back(LinearCombination(w));
+        for (auto &e : inst_) set.push_back(e);
+        if (one_hot.size() != set.size()) { cs.constrain(LinearCombination(Scalar::one())); return; }   // hadamard_product :112-131
+        LinearCombination prod(Scalar::zero());
+        for (size_t i = 0; i < set.size(); i++) { MulVars m = cs.multiply(one_hot[i], set[i]); prod = prod + LinearCombination(m.o); }
+        cs.constrain(value_ - prod);
+    }
+private:
+    LinearCombination value_; OptScalar va_; std::vector<LinearCombination> inst_; bool has_; std::vector<Scalar> inst_val_;
 };
 
 }  // namespace bpg

@@ -154,6 +154,12 @@ bpg_status bpg_bounds_check_new(const uint8_t *min_be, uint64_t min_len, const u
 bpg_status bpg_mimc_hash256_new(const bpg_lc *image, bpg_gadget **out);
 bpg_status bpg_merkle_tree256_new(const bpg_lc *root, const bpg_lc *instance_vars, uint64_t n_inst, const bpg_lc *witness_vars,
                                   uint64_t n_wit, const char *pattern, bpg_gadget **out);
+/* the remaining gadgets of the reference; assignment pointers may be NULL on the verifier side */
+bpg_status bpg_equality_new(const bpg_lc *right_hand, uint64_t n, bpg_gadget **out);
+bpg_status bpg_inequality_new(const bpg_lc *right_hand, uint64_t n, const uint8_t *right_assignment /* n x 32 or NULL */, bpg_gadget **out);
+bpg_status bpg_less_than_new(const bpg_lc *left, const uint8_t *left_assignment, const bpg_lc *right, const uint8_t *right_assignment, bpg_gadget **out);
+bpg_status bpg_set_membership_new(const bpg_lc *value, const uint8_t *value_assignment, const bpg_lc *instance_vars, uint64_t n_inst,
+                                  const uint8_t *instance_assignments /* n_inst x 32 or NULL */, bpg_gadget **out);
 void bpg_gadget_free(bpg_gadget *g);
 /* Gadget::setup: derived = preprocess(witnesses); one commitment each. *n_derived: in = capacity, out = count */
 bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *witness_scalars, uint64_t n_wit, const uint8_t *blindings,

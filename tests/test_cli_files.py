@@ -30,6 +30,11 @@ CASES = {
     "bounds_check": None,
     "mimc_hash": None,
     "merkle_tree": None,
+    "equality": None,
+    "inequality": None,
+    "less_than": (3 * 379, 3 * 763, None),
+    "set_membership": None,
+    "example": (14988, 30007, 33),          # SURVEY.md section 8 cfg 1: the reference's README example, all nine lines
     "example_subset": (16 + 972 + (972 + 1944) * 2 + 2 * 972 + 3 * 1944, 35 + 1946 + (1946 + 3889) * 2 + 2 * 1946 + 11665, None),
 }
 
@@ -43,6 +48,8 @@ def test_prover_then_verifier(ctx, tmp_path, name):
     p, proof = cli.prover(stem, ctx=ctx, seed=b"cli-test", rng_seed=bytes(32), quiet=True)
     if CASES[name]:
         assert (p.get_num_multiplications(), p.num_constraints()) == CASES[name][:2]
+        if CASES[name][2] is not None:
+            assert p.num_committed() == CASES[name][2]
     assert (tmp_path / (name + ".proof")).read_bytes() == proof
     coms = (tmp_path / (name + ".coms")).read_text().splitlines()
     assert len(coms) == p.num_committed() and all(l.startswith(("C", "D")) and " = 0x" in l for l in coms)

@@ -1,0 +1,130 @@
+"""Equality / Inequality / LessThan / SetMembership: the reference's positive and negative unit tests
+(src/equality/equality_gadget.rs:50-197, inequality_gadget.rs:115-419, less_than_gadget.rs:88-333, set_membership_gadget.rs:134-403)
+restated: prove on the GPU, byte-compare with the oracle, verify with the oracle AND the GPU verifier; unsatisfied statements
+must be rejected by both."""
+import hashlib
+import pytest
+import bulletproofs_gadgets_amd as bpg
+import oracle_lib as O
+import pyref as R
+
+pytestmark = pytest.mark.gpu
+sc = lambda x: (x % R.L).to_bytes(32, "little")
+rs = lambda tag, i: sc(int.from_bytes(hashlib.sha512(b"%s%d" % (tag, i)).digest(), "little"))
+H = bytes.fromhex
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return bpg.Context(0)
+
+
+def to_oracle(inst):
+    return O.FlatCircuit(inst.n, inst.m, inst.aL or None, inst.aR or None, inst.aO or None, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+
+
+def run(ctx, label, build_prover, build_verifier, capacity, expect_ok):
+    tp = bpg.Transcript(label)
+    p = bpg.Prover(ctx, tp)
+    coms = build_prover(p)
+    inst, state = p.instance(), tp.state
+    proof = p.prove(bpg.BulletproofGens(ctx, capacity), bytes(range(32)))
+    og = O.Gens(capacity)
+    rc, want, _ = O.prove(og, state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
+    assert rc == 0 and proof == want
+    assert O.satisfied(to_oracle(inst), inst.v) == expect_ok
+    tv = bpg.Transcript(label)
+    v = bpg.Verifier(tv)
+    build_verifier(v, coms)
+    vi = v.instance()
+    assert tv.state == state and vi.commitments == b"".join(coms)
+    assert (O.verify(og, tv.state, to_oracle(vi), vi.commitments, proof) == 0) == expect_ok
+    assert v.is_valid(proof, ctx, capacity) == expect_ok
+
+
+W_A = H("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb668749")
+LONG = bytes(range(1, 71))          # 70 bytes -> 3 scalars
+
+
+@pytest.mark.parametrize("left,right,ok", [(W_A, W_A, True), (W_A, W_A[:-1] + b"\x48", False), (LONG, LONG, True),
+                                           (LONG, LONG[:40] + b"\xff" + LONG[41:], False), (LONG, LONG[:33], False)])
+def test_equality_instance_right_hand(ctx, left, right, ok):
+    def bp(p):
+        self_ = {}
+        _, coms, vars_ = bpg.commit(p, left, [rs(b"eq", i) for i in range(4)])
+        bpg.Equality(bpg.be_to_scalars(right)).prove(p, vars_, [])
+        return coms
+
+    def bv(v, coms):
+        bpg.Equality(bpg.be_to_scalars(right)).verify(v, bpg.verifier_commit(v, coms), [])
+    run(ctx, b"Equality", bp, bv, 1, ok)
+
+
+def test_equality_witness_right_hand(ctx):
+    def bp(p):
+        _, c1, v1 = bpg.commit(p, LONG, [rs(b"e1", i) for i in range(3)])
+        _, c2, v2 = bpg.commit(p, LONG, [rs(b"e2", i) for i in range(3)])
+        bpg.Equality(v2).prove(p, v1, [])
+        return c1 + c2
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        bpg.Equality(vs[3:]).verify(v, vs[:3], [])
+    run(ctx, b"Equality", bp, bv, 1, True)
+
+
+@pytest.mark.parametrize("left,right,ok", [(W_A, W_A[:-1] + b"\x48", True), (W_A, W_A, False), (LONG, LONG[:69] + b"\x00", True), (LONG, LONG, False),
+                                           (b"\x05", b"\x07", True), (b"\x07", b"\x05", True)])
+def test_inequality(ctx, left, right, ok):
+    right_scalars = bpg.be_to_scalars(right)
+
+    def bp(p):
+        ls, coms, vars_ = bpg.commit(p, left, [rs(b"ne", i) for i in range(4)])
+        g = bpg.Inequality(right_scalars, right_scalars)
+        dc, dw = g.setup(p, ls, [rs(b"nd", i) for i in range(2 * len(ls) + 1)])
+        g.prove(p, vars_, dw)
+        return coms + dc
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        k = len(bpg.be_to_scalars(left))
+        bpg.Inequality(right_scalars, None).verify(v, vs[:k], vs[k:])
+    run(ctx, b"Inequality", bp, bv, 16, ok)
+
+
+@pytest.mark.parametrize("left,right,ok", [(3, 5, True), (5, 3, False), (7, 7, False), (0, 1, True), (2**126 - 2, 2**126 - 1, True),
+                                           (5, 2**126 + 5, False), (2**125, 2**125 + 2**60, True)])
+def test_less_than(ctx, left, right, ok):
+    lb, rb = left.to_bytes(17, "big"), right.to_bytes(17, "big")
+
+    def bp(p):
+        ls, lc, lv = bpg.commit_single(p, lb, rs(b"lt", 0))
+        rs_, rc, rv = bpg.commit_single(p, rb, rs(b"lt", 1))
+        g = bpg.LessThan(lv, ls, rv, rs_)
+        dc, dw = g.setup(p, [], [rs(b"lt", 2), rs(b"lt", 3)])
+        g.prove(p, [], dw)
+        return [lc, rc] + dc
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        bpg.LessThan(vs[0], None, vs[1], None).verify(v, [], vs[2:])
+    run(ctx, b"LessThan", bp, bv, 512, ok)
+
+
+@pytest.mark.parametrize("member,ok", [(b"\x43", True), (b"\x11", True), (b"\x64", True), (b"\x44", False)])
+def test_set_membership(ctx, member, ok):
+    inst_set = [bpg.be_to_scalar(b"\x11"), bpg.be_to_scalar(b"\x64")]       # example.gadgets:8 style: instances and witnesses mixed
+    wit_set = [b"\x43", b"\x0e\x44"]
+
+    def bp(p):
+        ms, mc, mv = bpg.commit_single(p, member, rs(b"sm", 0))
+        ws, wc, wv = bpg.commit_all_single(p, wit_set, [rs(b"sm", 1), rs(b"sm", 2)])
+        g = bpg.SetMembership(mv, ms, inst_set, inst_set)
+        dc, dw = g.setup(p, ws, [rs(b"sd", i) for i in range(4)])
+        g.prove(p, wv, dw)
+        return [mc] + wc + dc
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        bpg.SetMembership(vs[0], None, inst_set, None).verify(v, vs[1:3], vs[3:])
+    run(ctx, b"SetMembership", bp, bv, 8, ok)
