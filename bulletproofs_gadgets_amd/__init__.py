@@ -450,6 +450,39 @@ class Verifier:
             self._h = None
 
 
+class ConstraintBuffer:
+    """ProverBuffer / VerifierBuffer of the reference (src/cs_buffer.rs): records a clause's operations for an OR block."""
+
+    def __init__(self, parent, prover_side: bool):
+        first = parent.next_multiplier() if isinstance(parent, ConstraintBuffer) else \
+            (parent.get_num_multiplications() if isinstance(parent, Prover) else parent.get_num_vars())
+        self.prover_side = prover_side
+        self._h = C.c_void_p()
+        _chk(lib().bpg_buffer_new(C.c_uint64(first), C.c_int32(1 if prover_side else 0), C.byref(self._h)))
+
+    def rewind(self):
+        _chk(lib().bpg_buffer_rewind(self._h))
+
+    def next_multiplier(self):
+        lib().bpg_buffer_next_multiplier.restype = C.c_uint64
+        return lib().bpg_buffer_next_multiplier(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().bpg_buffer_free(self._h)
+            self._h = None
+
+
+def or_conjunction(main, buffer: ConstraintBuffer):
+    """or(main, buffer) (src/or/or_conjunction.rs:4-38): main is a Prover, a Verifier or an enclosing ConstraintBuffer."""
+    if isinstance(main, ConstraintBuffer):
+        _chk(lib().bpg_or_buffer(main._h, buffer._h))
+    elif isinstance(main, Prover):
+        _chk(lib().bpg_or_prover(main._h, buffer._h))
+    else:
+        _chk(lib().bpg_or_verifier(main._h, buffer._h))
+
+
 class PedersenGens:
     """PedersenGens::default() - the bases live in the Context."""
     def __init__(self, ctx: Context): self.ctx = ctx
@@ -506,16 +539,19 @@ class Gadget:
         k = n.value
         return [coms.raw[32 * i:32 * i + 32] for i in range(k)], [(dsc.raw[32 * i:32 * i + 32], Variable(dvars[i])) for i in range(k)]
 
-    def prove(self, prover: Prover, commitment_vars, derived_witnesses):
+    def prove(self, prover, commitment_vars, derived_witnesses):
+        """Gadget::prove on a Prover or on a ConstraintBuffer (the dyn ConstraintSystem of the reference)."""
         v = (C.c_uint32 * max(len(commitment_vars), 1))(*[int(x) for x in commitment_vars])
         dv = (C.c_uint32 * max(len(derived_witnesses), 1))(*[int(x[1]) for x in derived_witnesses])
-        _chk(lib().bpg_gadget_prove(self._h, prover._h, v, C.c_uint64(len(commitment_vars)), b"".join(x[0] for x in derived_witnesses),
-                                    dv, C.c_uint64(len(derived_witnesses))))
+        fn = lib().bpg_gadget_prove_buffered if isinstance(prover, ConstraintBuffer) else lib().bpg_gadget_prove
+        _chk(fn(self._h, prover._h, v, C.c_uint64(len(commitment_vars)), b"".join(x[0] for x in derived_witnesses),
+                dv, C.c_uint64(len(derived_witnesses))))
 
-    def verify(self, verifier: Verifier, witnesses, derived):
+    def verify(self, verifier, witnesses, derived):
         v = (C.c_uint32 * max(len(witnesses), 1))(*[int(x) for x in witnesses])
         dv = (C.c_uint32 * max(len(derived), 1))(*[int(x) for x in derived])
-        _chk(lib().bpg_gadget_verify(self._h, verifier._h, v, C.c_uint64(len(witnesses)), dv, C.c_uint64(len(derived))))
+        fn = lib().bpg_gadget_verify_buffered if isinstance(verifier, ConstraintBuffer) else lib().bpg_gadget_verify
+        _chk(fn(self._h, verifier._h, v, C.c_uint64(len(witnesses)), dv, C.c_uint64(len(derived))))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -9,14 +9,15 @@ written as "C{id}-{k} = 0x.." (assignment_parser.rs:152-169,213-220); derived co
 MERKLE hashes every W leaf through hash_witness (prover.rs:160-190) and every I leaf through mimc_hash (prover.rs:192-200);
 generators: round_pow2(#multipliers) (prover.rs:43-45,92). The shadow ProverBuffer of the reference only exists to support OR
 blocks (not in this subset); recording and replaying its operations is the identity on multiplier / constraint order.
-EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN follow prover.rs:340-532 and verifier.rs:262-424 (row f3); OR blocks are not implemented.
+EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN follow prover.rs:340-532 and verifier.rs:262-424; OR [ { .. } { .. } ] blocks (also nested)
+follow prover.rs:202-238 / or_conjunction.rs:4-38 with a recording ConstraintBuffer per block (row f3).
 """
 import hashlib
 import os
 import re
 import sys
 
-from . import (BoundsCheck, BulletproofGens, Context, Equality, Inequality, LessThan, MerkleTree256, MimcHash256, Prover,
+from . import (BoundsCheck, BulletproofGens, ConstraintBuffer, Context, Equality, or_conjunction, Inequality, LessThan, MerkleTree256, MimcHash256, Prover,
                SetMembership, Transcript, Verifier, be_to_scalar, be_to_scalars, commit, commit_single, mimc_hash, scalar_to_be, L)
 
 _VAR = re.compile(r"^\s*([A-Za-z][0-9]+(?:-[0-9]+){0,2})\s*=\s*0[xX]([0-9a-fA-F]+)\s*$")
@@ -115,51 +116,51 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
         assert len(data) <= 32, "instance var %s is longer than 32 bytes" % token
         return be_to_scalar(data)
 
-    def hash_witness(wn, index, sub):                                     # prover.rs:160-190 -> (image scalar, image Variable)
+    def hash_witness(wn, index, sub, cs):                                 # prover.rs:160-190 -> (image scalar, image Variable)
         w = witness[wn]
         image = mimc_hash(w[3])
         _, image_com, image_var = commit_single(p, scalar_to_be(image), rnd.next())
         hg = MimcHash256(image_var)
         dcoms, derived = hg.setup(p, w[0], rnd.take(2))
-        hg.prove(p, w[2], derived)
+        hg.prove(cs, w[2], derived)
         derived_lines([image_com] + dcoms, index, sub)
         return image, image_var
 
     with open(name + ".gadgets") as f:
         lines = [l.rstrip("\n") for l in f]
-    for index, line in enumerate(lines):
+
+    def do_gadget(line, index, cs):
+        """one gadget line: commitments always go to the real prover p, constraints to cs (p itself or an OR-block buffer)"""
         parts = line.split()
-        if not parts:
-            continue
         op = parts[0]
         if op == "BOUND":                                                 # prover.rs:253-276
             w = single(parts[1])
             lo, hi = instance[parts[2]], instance[parts[3]]
             g = BoundsCheck(lo, hi)
             dcoms, derived = g.setup(p, w[0], rnd.take(2))
-            g.prove(p, w[2], derived)
+            g.prove(cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "HASH":                                                # prover.rs:278-305
             g = MimcHash256(lc_of(parts[1]))
             w = witness[parts[2]]
             dcoms, derived = g.setup(p, w[0], rnd.take(2))
-            g.prove(p, w[2], derived)
+            g.prove(cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "MERKLE":                                              # prover.rs:307-339
             root = lc_of(parts[1])
             inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
             inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
-            wit_lcs = [hash_witness(wn, index, sub)[1] for sub, wn in enumerate(wit_names)]
-            MerkleTree256(root, inst_lcs, wit_lcs, pattern).prove(p, [], [])
+            wit_lcs = [hash_witness(wn, index, sub, cs)[1] for sub, wn in enumerate(wit_names)]
+            MerkleTree256(root, inst_lcs, wit_lcs, pattern).prove(cs, [], [])
         elif op == "EQUALS":                                              # prover.rs:340-358 (grammar: W I | I W | W W)
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
             right_lcs = witness[right][2] if right[0] == "W" else be_to_scalars(instance[right])
-            Equality(right_lcs).prove(p, witness[left][2], [])
+            Equality(right_lcs).prove(cs, witness[left][2], [])
         elif op == "LESS_THAN":                                           # prover.rs:360-382
             l, r = single(parts[1]), single(parts[2])
             g = LessThan(l[2][0], l[0][0], r[2][0], r[0][0])
             dcoms, derived = g.setup(p, [], rnd.take(2))
-            g.prove(p, [], derived)
+            g.prove(cs, [], derived)
             derived_lines(dcoms, index, 0)
         elif op == "UNEQUAL":                                             # prover.rs:384-418
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
@@ -170,7 +171,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
                 rs_ = be_to_scalars(instance[right]); rl = rs_
             g = Inequality(rl, rs_)
             dcoms, derived = g.setup(p, lw[0], rnd.take(2 * len(lw[0]) + 1))
-            g.prove(p, lw[2], derived)
+            g.prove(cs, lw[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "SET_MEMBER":                                          # prover.rs:420-532
             member, elems = parts[1], parts[2:]
@@ -197,22 +198,48 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             if hashing:                                                   # elements longer than one scalar: compare MiMC images
                 sub = 1
                 if member[0] == "W":
-                    m_scalar, m_lc = hash_witness(member, index, sub); sub += 1
+                    m_scalar, m_lc = hash_witness(member, index, sub, cs); sub += 1
                 else:
                     m_scalar = mimc_hash(instance[member]); m_lc = m_scalar
                 w_vars, w_scalars, i_lcs, i_scalars = [], [], [], []
                 for e in elems:
                     if e[0] == "W":
-                        sc_, var = hash_witness(e, index, sub); sub += 1
+                        sc_, var = hash_witness(e, index, sub, cs); sub += 1
                         w_vars.append(var); w_scalars.append(sc_)
                     else:
                         h = mimc_hash(instance[e]); i_lcs.append(h); i_scalars.append(h)
             g = SetMembership(m_lc, m_scalar, i_lcs, i_scalars)
             dcoms, derived = g.setup(p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars)))
-            g.prove(p, w_vars, derived)
+            g.prove(cs, w_vars, derived)
             derived_lines(dcoms, index, 0)
         else:
             raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
+
+    def run_block(i, cs, closing):
+        """lines from i on; closing = None at top level, "]" inside an OR block (prover.rs:75-84 and :219-234)"""
+        while i < len(lines):
+            line, index = lines[i], i
+            i += 1
+            parts = line.split()
+            if not parts:
+                continue
+            op = parts[0]
+            if closing is not None and op == closing:
+                return i
+            if op == "}":
+                cs.rewind()                                               # end of a clause
+            elif op == "OR":
+                child = ConstraintBuffer(cs, True)
+                i = run_block(i, child, "]")
+                or_conjunction(cs, child)
+            elif op in ("[", "{"):
+                pass
+            else:
+                do_gadget(line, index, cs)
+        if closing is not None:
+            raise ValueError("unexpected end of input")
+        return i
+    run_block(0, p, None)
     if not quiet:
         print(p.num_constraints())                                        # prover.rs:89
     cap = round_pow2(p.get_num_multiplications())
@@ -257,40 +284,39 @@ def assemble_verifier(name):
             out.append(commitments[key])
         return out
 
-    def hash_witness(wn, index, sub):                                     # verifier.rs:426-444 -> image Variable
+    def hash_witness(wn, index, sub, cs):                                 # verifier.rs:426-444 -> image Variable
         d = derived(index, sub, 3)
-        MimcHash256(d[0]).verify(v, all_commitments(wn), d[1:])
+        MimcHash256(d[0]).verify(cs, all_commitments(wn), d[1:])
         return d[0]
 
     with open(name + ".gadgets") as f:
         lines = [l.rstrip("\n") for l in f]
-    for index, line in enumerate(lines):
+
+    def do_gadget(line, index, cs):
         parts = line.split()
-        if not parts:
-            continue
         op = parts[0]
         if op == "BOUND":                                                 # verifier.rs:188-205
-            BoundsCheck(instance[parts[2]], instance[parts[3]]).verify(v, [commitments["C%s-0" % parts[1][1:]]], derived(index, 0, 2))
+            BoundsCheck(instance[parts[2]], instance[parts[3]]).verify(cs, [commitments["C%s-0" % parts[1][1:]]], derived(index, 0, 2))
         elif op == "HASH":                                                # verifier.rs:207-230
-            MimcHash256(lc_of(parts[1])).verify(v, all_commitments(parts[2]), derived(index, 0, 2))
+            MimcHash256(lc_of(parts[1])).verify(cs, all_commitments(parts[2]), derived(index, 0, 2))
         elif op == "MERKLE":                                              # verifier.rs:232-260
             root = lc_of(parts[1])
             inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
             inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
-            wit_lcs = [hash_witness(wn, index, sub) for sub, wn in enumerate(wit_names)]
-            MerkleTree256(root, inst_lcs, wit_lcs, pattern).verify(v, [], [])
+            wit_lcs = [hash_witness(wn, index, sub, cs) for sub, wn in enumerate(wit_names)]
+            MerkleTree256(root, inst_lcs, wit_lcs, pattern).verify(cs, [], [])
         elif op == "EQUALS":                                              # verifier.rs:262-280
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
             right_lcs = all_commitments(right) if right[0] == "W" else be_to_scalars(instance[right])
-            Equality(right_lcs).verify(v, all_commitments(left), [])
+            Equality(right_lcs).verify(cs, all_commitments(left), [])
         elif op == "LESS_THAN":                                           # verifier.rs:282-301
-            LessThan(commitments["C%s-0" % parts[1][1:]], None, commitments["C%s-0" % parts[2][1:]], None).verify(v, [], derived(index, 0, 2))
+            LessThan(commitments["C%s-0" % parts[1][1:]], None, commitments["C%s-0" % parts[2][1:]], None).verify(cs, [], derived(index, 0, 2))
         elif op == "UNEQUAL":                                             # verifier.rs:303-332
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
             lv = all_commitments(left)
             right_lcs = all_commitments(right) if right[0] == "W" else be_to_scalars(instance[right])
             d = [commitments["D%d-0-%d" % (index, k)] for k in range(2 * len(lv) + 1)]
-            Inequality(right_lcs, None).verify(v, lv, d)
+            Inequality(right_lcs, None).verify(cs, lv, d)
         elif op == "SET_MEMBER":                                          # verifier.rs:334-424
             member, elems = parts[1], parts[2:]
             m_lcs = all_commitments(member) if member[0] == "W" else be_to_scalars(instance[member])
@@ -316,18 +342,43 @@ def assemble_verifier(name):
             if hashing:
                 sub = 1
                 if member[0] == "W":
-                    m_lc = hash_witness(member, index, sub); sub += 1
+                    m_lc = hash_witness(member, index, sub, cs); sub += 1
                 else:
                     m_lc = mimc_hash(instance[member])
                 w_vars, i_lcs = [], []
                 for e in elems:
                     if e[0] == "W":
-                        w_vars.append(hash_witness(e, index, sub)); sub += 1
+                        w_vars.append(hash_witness(e, index, sub, cs)); sub += 1
                     else:
                         i_lcs.append(mimc_hash(instance[e]))
-            SetMembership(m_lc, None, i_lcs, None).verify(v, w_vars, d)
+            SetMembership(m_lc, None, i_lcs, None).verify(cs, w_vars, d)
         else:
             raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
+
+    def run_block(i, cs, closing):
+        while i < len(lines):
+            line, index = lines[i], i
+            i += 1
+            parts = line.split()
+            if not parts:
+                continue
+            op = parts[0]
+            if closing is not None and op == closing:
+                return i
+            if op == "}":
+                cs.rewind()
+            elif op == "OR":                                              # verifier.rs:162-186
+                child = ConstraintBuffer(cs, False)
+                i = run_block(i, child, "]")
+                or_conjunction(cs, child)
+            elif op in ("[", "{"):
+                pass
+            else:
+                do_gadget(line, index, cs)
+        if closing is not None:
+            raise ValueError("unexpected end of input")
+        return i
+    run_block(0, v, None)
     return v, transcript
 
 

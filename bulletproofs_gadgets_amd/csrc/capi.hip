@@ -75,6 +75,7 @@ struct bpg_transcript { Transcript t; };
 struct bpg_prover { Prover *p; FlatCircuit flat; std::vector<uint8_t> v_bytes, vb_bytes; };
 struct bpg_verifier { Verifier *v; FlatCircuit flat; };
 struct bpg_gadget { std::unique_ptr<Gadget> g; };
+struct bpg_buffer { OpBuffer b; };
 
 static thread_local std::string g_last_error;
 
@@ -401,6 +402,24 @@ bpg_status bpg_gadget_verify(bpg_gadget *g, bpg_verifier *v, const uint32_t *var
         g->g->verify(*v->v, unpack_vars(vars, n_vars), unpack_vars(dvars, n_derived));
     });
 }
+bpg_status bpg_buffer_new(uint64_t first, int32_t prover_side, bpg_buffer **out) { return guard([&] { REQUIRE(out); *out = new bpg_buffer{OpBuffer(first, prover_side != 0)}; }); }
+void bpg_buffer_free(bpg_buffer *b) { delete b; }
+bpg_status bpg_buffer_rewind(bpg_buffer *b) { return guard([&] { REQUIRE(b); b->b.rewind(); }); }
+uint64_t bpg_buffer_next_multiplier(const bpg_buffer *b) { return b ? b->b.next_multiplier() : 0; }
+bpg_status bpg_gadget_prove_buffered(bpg_gadget *g, bpg_buffer *b, const uint32_t *vars, uint64_t n_vars, const uint8_t *dsc, const uint32_t *dvars, uint64_t n_derived) {
+    return guard([&] {
+        REQUIRE(g && b && (n_vars == 0 || vars) && (n_derived == 0 || (dsc && dvars)));
+        Derived d;
+        for (uint64_t i = 0; i < n_derived; i++) d.emplace_back(OptScalar(Scalar::from_bits(dsc + 32 * i)), Variable::unpack(dvars[i]));
+        g->g->prove(b->b, unpack_vars(vars, n_vars), d);
+    });
+}
+bpg_status bpg_gadget_verify_buffered(bpg_gadget *g, bpg_buffer *b, const uint32_t *vars, uint64_t n_vars, const uint32_t *dvars, uint64_t n_derived) {
+    return guard([&] { REQUIRE(g && b && (n_vars == 0 || vars) && (n_derived == 0 || dvars)); g->g->verify(b->b, unpack_vars(vars, n_vars), unpack_vars(dvars, n_derived)); });
+}
+bpg_status bpg_or_prover(bpg_prover *main, const bpg_buffer *b) { return guard([&] { REQUIRE(main && b); or_conjunction(*main->p, b->b); }); }
+bpg_status bpg_or_verifier(bpg_verifier *main, const bpg_buffer *b) { return guard([&] { REQUIRE(main && b); or_conjunction(*main->v, b->b); }); }
+bpg_status bpg_or_buffer(bpg_buffer *parent, const bpg_buffer *b) { return guard([&] { REQUIRE(parent && b); or_conjunction(parent->b, b->b); }); }
 bpg_status bpg_range_proof_prove(bpg_prover *p, const bpg_lc *x, uint32_t n_bits, const uint8_t a[32]) {
     return guard([&] { REQUIRE(p && a && n_bits <= 255); range_proof(*p->p, lc_from(x), (uint8_t)n_bits, OptScalar(Scalar::from_bits(a))); });
 }

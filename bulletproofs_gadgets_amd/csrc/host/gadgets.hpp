@@ -13,6 +13,7 @@
 //   Inequality         src/inequality/inequality_gadget.rs:5-113
 //   LessThan           src/less_than/less_than_gadget.rs:6-86
 //   SetMembership      src/set_membership/set_membership_gadget.rs:5-132
+//   OpBuffer / or_conjunction   src/cs_buffer.rs:5-113, src/or/or_conjunction.rs:4-67
 #pragma once
 #include <memory>
 #include "r1cs.hpp"
@@ -340,5 +341,65 @@ public:
 private:
     LinearCombination value_; OptScalar va_; std::vector<LinearCombination> inst_; bool has_; std::vector<Scalar> inst_val_;
 };
+
+// ------------------------------------------------------------------------------------------ cs_buffer.rs / or_conjunction.rs
+// Recording constraint system for OR blocks.  The reference wraps a throw-away shadow Prover/Verifier whose only observable
+// effect is the numbering of the multiplier variables it hands out; here that numbering is a counter that starts at the
+// parent's current multiplier count (what the reference reaches by replaying `initialization` into the shadow).
+struct BufferedOp {
+    enum Kind { Multiply, AllocateMultiplier, Constrain } kind;
+    LinearCombination a, b;            // Multiply: (left, right); Constrain: a
+    bool some = false; Scalar l, r;    // AllocateMultiplier
+};
+class OpBuffer : public ConstraintSystem {
+public:
+    OpBuffer(uint64_t first_multiplier, bool prover_side) : next_(first_multiplier), prover_(prover_side) {}
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        BufferedOp op; op.kind = BufferedOp::Multiply; op.a = std::move(left); op.b = std::move(right); ops_.push_back(std::move(op));
+        return vars(next_++);
+    }
+    Variable allocate(const OptScalar &) override { throw R1CSException(R1CSError::GadgetError, "call to unimplemented method allocate"); }   // cs_buffer.rs:99-101
+    MulVars allocate_multiplier(bool some, const Scalar &l, const Scalar &r) override {
+        if (prover_ && !some) throw R1CSException(R1CSError::MissingAssignment, "missing assignment");   // cs_buffer.rs:103-104
+        BufferedOp op; op.kind = BufferedOp::AllocateMultiplier; op.some = some && prover_; op.l = l; op.r = r; ops_.push_back(std::move(op));
+        return vars(next_++);
+    }
+    void constrain(const LinearCombination &lc) override { BufferedOp op; op.kind = BufferedOp::Constrain; op.a = lc; ops_.push_back(std::move(op)); }
+    void rewind() { cached_.push_back(std::move(ops_)); ops_.clear(); }                              // cs_buffer.rs:75-78
+    const std::vector<std::vector<BufferedOp>> &cache() const { return cached_; }
+    uint64_t next_multiplier() const { return next_; }
+private:
+    static MulVars vars(uint64_t i) { uint32_t k = (uint32_t)i; return MulVars{{Variable::MultiplierLeft, k}, {Variable::MultiplierRight, k}, {Variable::MultiplierOutput, k}}; }
+    uint64_t next_; bool prover_;
+    std::vector<BufferedOp> ops_;
+    std::vector<std::vector<BufferedOp>> cached_;
+};
+
+// or(main, buffer): replay every clause's multipliers into main, then constrain the product of one constraint per clause to
+// zero for every element of the Cartesian product (last clause varying fastest, as the reference's fold does)
+inline void or_conjunction(ConstraintSystem &main, const OpBuffer &buffer) {
+    std::vector<std::vector<const LinearCombination *>> sets;
+    for (const auto &clause : buffer.cache()) {
+        std::vector<const LinearCombination *> cons;
+        for (const BufferedOp &op : clause) {
+            switch (op.kind) {
+            case BufferedOp::Multiply: main.multiply(op.a, op.b); break;
+            case BufferedOp::AllocateMultiplier: main.allocate_multiplier(op.some, op.l, op.r); break;
+            case BufferedOp::Constrain: cons.push_back(&op.a); break;
+            }
+        }
+        sets.push_back(std::move(cons));
+    }
+    if (sets.empty()) return;
+    for (auto &c : sets) if (c.empty()) return;               // empty factor: empty product
+    std::vector<size_t> idx(sets.size(), 0);
+    for (;;) {
+        LinearCombination prod = *sets[0][idx[0]];
+        for (size_t k = 1; k < sets.size(); k++) { MulVars m = main.multiply(prod, *sets[k][idx[k]]); prod = LinearCombination(m.o); }
+        main.constrain(prod);
+        size_t k = sets.size();
+        while (k > 0) { k--; if (++idx[k] < sets[k].size()) break; idx[k] = 0; if (k == 0) return; }
+    }
+}
 
 }  // namespace bpg

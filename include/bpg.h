@@ -167,6 +167,19 @@ bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *witness
 bpg_status bpg_gadget_prove(bpg_gadget *g, bpg_prover *p, const uint32_t *vars, uint64_t n_vars, const uint8_t *derived_scalars,
                             const uint32_t *derived_vars, uint64_t n_derived);
 bpg_status bpg_gadget_verify(bpg_gadget *g, bpg_verifier *v, const uint32_t *vars, uint64_t n_vars, const uint32_t *derived_vars, uint64_t n_derived);
+/* OR blocks (reference src/cs_buffer.rs, src/or/or_conjunction.rs): a recording constraint system whose multiplier numbering
+ * starts at the parent's current multiplier count; rewind() closes a clause; bpg_or_* replays the clauses into the parent. */
+typedef struct bpg_buffer bpg_buffer;
+bpg_status bpg_buffer_new(uint64_t first_multiplier, int32_t prover_side, bpg_buffer **out);
+void bpg_buffer_free(bpg_buffer *b);
+bpg_status bpg_buffer_rewind(bpg_buffer *b);
+uint64_t bpg_buffer_next_multiplier(const bpg_buffer *b);
+bpg_status bpg_gadget_prove_buffered(bpg_gadget *g, bpg_buffer *b, const uint32_t *vars, uint64_t n_vars, const uint8_t *derived_scalars,
+                                     const uint32_t *derived_vars, uint64_t n_derived);
+bpg_status bpg_gadget_verify_buffered(bpg_gadget *g, bpg_buffer *b, const uint32_t *vars, uint64_t n_vars, const uint32_t *derived_vars, uint64_t n_derived);
+bpg_status bpg_or_prover(bpg_prover *main, const bpg_buffer *b);
+bpg_status bpg_or_verifier(bpg_verifier *main, const bpg_buffer *b);
+bpg_status bpg_or_buffer(bpg_buffer *parent, const bpg_buffer *b);
 /* utils::range_proof(cs, x, n, x_assignment) on a prover (assignment given) or a verifier (none) */
 bpg_status bpg_range_proof_prove(bpg_prover *p, const bpg_lc *x, uint32_t n_bits, const uint8_t assignment[32]);
 bpg_status bpg_range_proof_verify(bpg_verifier *v, const bpg_lc *x, uint32_t n_bits);

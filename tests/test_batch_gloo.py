@@ -6,6 +6,13 @@ import subprocess
 import sys
 import textwrap
 import pathlib
+import socket
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 
@@ -61,7 +68,7 @@ def test_two_rank_gloo_batch(tmp_path):
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29611", str(script)]
+           "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout

@@ -128,3 +128,63 @@ def test_set_membership(ctx, member, ok):
         vs = bpg.verifier_commit(v, coms)
         bpg.SetMembership(vs[0], None, inst_set, None).verify(v, vs[1:3], vs[3:])
     run(ctx, b"SetMembership", bp, bv, 8, ok)
+
+
+def test_or_conjunction_of_hash_clauses(ctx):
+    """reference src/or/or_conjunction.rs:84-190: three MiMC preimage clauses, only some of them true; the disjunction verifies
+    iff at least one clause holds. (Small images here: 1-block preimages -> 1,946 constraints per clause.)"""
+    pre = [b"alpha", b"beta", b"gamma"]
+
+    def build(claims_true):
+        images = [bpg.mimc_hash(x) if t else bpg.mimc_hash(x + b"!") for x, t in zip(pre, claims_true)]
+
+        def bp(p):
+            buf = bpg.ConstraintBuffer(p, True)
+            coms = []
+            for k, (x, img) in enumerate(zip(pre, images)):
+                g = bpg.MimcHash256(img)
+                sc_, wc, wv = bpg.commit(p, x, [rs(b"or%d" % k, 0)])
+                dc, dw = g.setup(p, sc_, [rs(b"or%d" % k, 1), rs(b"or%d" % k, 2)])
+                g.prove(buf, wv, dw)
+                buf.rewind()
+                coms += wc + dc
+            bpg.or_conjunction(p, buf)
+            return coms
+
+        def bv(v, coms):
+            buf = bpg.ConstraintBuffer(v, False)
+            vs = bpg.verifier_commit(v, coms)
+            for k, img in enumerate(images):
+                bpg.MimcHash256(img).verify(buf, [vs[3 * k]], vs[3 * k + 1:3 * k + 3])
+                buf.rewind()
+            bpg.or_conjunction(v, buf)
+        return bp, bv
+    # 3 clauses x 1,946 constraints would give 7.4e9 products; use two clauses (3.8 M products) only for the true/false matrix on
+    # a smaller gadget: BOUND (35 constraints) x BOUND x BOUND = 42,875 products
+    lo, hi = bytes([10]), bytes([100])
+
+    def build_bounds(values):
+        def bp(p):
+            buf = bpg.ConstraintBuffer(p, True)
+            coms = []
+            for k, val in enumerate(values):
+                g = bpg.BoundsCheck(lo, hi)
+                sc_, wc, wv = bpg.commit(p, bytes([val]), [rs(b"ob%d" % k, 0)])
+                dc, dw = g.setup(p, sc_, [rs(b"ob%d" % k, 1), rs(b"ob%d" % k, 2)])
+                g.prove(buf, wv, dw)
+                buf.rewind()
+                coms += wc + dc
+            bpg.or_conjunction(p, buf)
+            return coms
+
+        def bv(v, coms):
+            buf = bpg.ConstraintBuffer(v, False)
+            vs = bpg.verifier_commit(v, coms)
+            for k in range(len(values)):
+                bpg.BoundsCheck(lo, hi).verify(buf, [vs[3 * k]], vs[3 * k + 1:3 * k + 3])
+                buf.rewind()
+            bpg.or_conjunction(v, buf)
+        return bp, bv
+    for values, ok in (([50, 5], True), ([5, 50], True), ([50, 60], True), ([5, 200], False)):
+        bp, bv = build_bounds(values)
+        run(ctx, b"OrBounds", bp, bv, 2048, ok)
