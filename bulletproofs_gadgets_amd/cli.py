@@ -1,14 +1,13 @@
-"""File driver for the reference's CLI formats, BOUND / HASH / MERKLE subset.
+"""File driver for the reference's CLI formats: all seven gadget lines and OR blocks.
 
     python -m bulletproofs_gadgets_amd.cli prover   NAME      reads NAME.gadgets/.inst/.wtns, writes NAME.coms/.proof
     python -m bulletproofs_gadgets_amd.cli verifier NAME      reads NAME.gadgets/.inst/.coms/.proof, prints true/false
 
-Mirrors reference src/bin/prover.rs:47-100 and src/bin/verifier.rs:46-101 for the three gadget kinds of the benchmark
-configurations: the transcript label is the NAME argument (prover.rs:49-52); witnesses are committed in .wtns order and
+Mirrors reference src/bin/prover.rs:47-100 and src/bin/verifier.rs:46-101 : the transcript label is the NAME argument (prover.rs:49-52); witnesses are committed in .wtns order and
 written as "C{id}-{k} = 0x.." (assignment_parser.rs:152-169,213-220); derived commitments as "D{line}-{sub}-{k}";
 MERKLE hashes every W leaf through hash_witness (prover.rs:160-190) and every I leaf through mimc_hash (prover.rs:192-200);
-generators: round_pow2(#multipliers) (prover.rs:43-45,92). The shadow ProverBuffer of the reference only exists to support OR
-blocks (not in this subset); recording and replaying its operations is the identity on multiplier / constraint order.
+generators: round_pow2(#multipliers) (prover.rs:43-45,92). The top-level shadow ProverBuffer of the reference (prover.rs:66-86) records every operation
+and replays it into the real prover at the end, which is the identity on multiplier / constraint order: top-level lines go to the prover directly.
 EQUALS / UNEQUAL / SET_MEMBER / LESS_THAN follow prover.rs:340-532 and verifier.rs:262-424; OR [ { .. } { .. } ] blocks (also nested)
 follow prover.rs:202-238 / or_conjunction.rs:4-38 with a recording ConstraintBuffer per block (row f3).
 """
@@ -213,7 +212,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             g.prove(cs, w_vars, derived)
             derived_lines(dcoms, index, 0)
         else:
-            raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
+            raise ValueError("unknown gadget line: %r" % line)
 
     def run_block(i, cs, closing):
         """lines from i on; closing = None at top level, "]" inside an OR block (prover.rs:75-84 and :219-234)"""
@@ -353,7 +352,7 @@ def assemble_verifier(name):
                         i_lcs.append(mimc_hash(instance[e]))
             SetMembership(m_lc, None, i_lcs, None).verify(cs, w_vars, d)
         else:
-            raise NotImplementedError("gadget %s is not supported (OR blocks: SURVEY.md 8f row f3)" % op)
+            raise ValueError("unknown gadget line: %r" % line)
 
     def run_block(i, cs, closing):
         while i < len(lines):

@@ -34,6 +34,7 @@ CASES = {
     "inequality": None,
     "less_than": (3 * 379, 3 * 763, None),
     "set_membership": None,
+    "or": None, "or2": None, "or4": None, "or5": (4721, 10531, 29),   # OR blocks: clauses 37 x 6 x 1 x 5 explicit constraints -> 1110 products
     "or3": None,                             # nested OR over EQUALS clauses (reference tests/resources/or3.*)
     "example": (14988, 30007, 33),          # SURVEY.md section 8 cfg 1: the reference's README example, all nine lines
     "example_subset": (16 + 972 + (972 + 1944) * 2 + 2 * 972 + 3 * 1944, 35 + 1946 + (1946 + 3889) * 2 + 2 * 1946 + 11665, None),
