@@ -390,7 +390,7 @@ inline void or_conjunction(ConstraintSystem &main, const OpBuffer &buffer) {
         }
         sets.push_back(std::move(cons));
     }
-    if (getenv("BPG_DEBUG_OR")) { fprintf(stderr, "or: %zu clauses:", sets.size()); for (auto &c : sets) fprintf(stderr, " %zu", c.size()); fprintf(stderr, "\n"); }
+
     if (sets.empty()) return;
     for (auto &c : sets) if (c.empty()) return;               // empty factor: empty product
     std::vector<size_t> idx(sets.size(), 0);

@@ -109,3 +109,30 @@ def merkle_full_tree(ctx, leaves=512, seed=None, label=b"MerkleTree"):
     a = Assembled(p, t, wcoms, cap, replay)
     a.root = root
     return a
+
+
+def merkle_path_files(stem: str, depth=20, wbytes=16, seed=0):
+    """cfg 4b: a depth-`depth` Merkle authentication path through the file driver,
+    `MERKLE I0 ((..((W0 I1) I2)..) I{depth})` (reference src/bin/prover.rs:307-339). Writes stem.gadgets/.inst/.wtns.
+    W0 (< 32 bytes: one absorbed block) is hashed by hash_witness, every sibling I_k by mimc_hash (prover.rs:160-200):
+    n = depth*1944 + 972 multipliers."""
+    from . import mimc_hash
+    cfg = "cfg4b-%s" % seed
+    w0 = synth(cfg, 0, wbytes)
+    sib = [synth(cfg, k, 24) for k in range(1, depth + 1)]
+    tree, pat = "W0", "I"
+    for k in range(1, depth + 1):
+        tree = "(%s I%d)" % (tree, k)
+        pat = hash_pattern(pat, "I")
+    probe = Prover(None, Transcript(b"probe"))
+    MerkleTree256(bytes(32), [mimc_hash(w0)] + [mimc_hash(s) for s in sib], [], pat).prove(probe, [], [])
+    root_le = probe.instance().aO[-32:]
+    with open(stem + ".gadgets", "w") as f:
+        f.write("MERKLE I0 %s\n" % tree)
+    with open(stem + ".inst", "w") as f:
+        f.write("I0 = 0x%s\n" % root_le[::-1].hex())
+        for k, s in enumerate(sib, 1):
+            f.write("I%d = 0x%s\n" % (k, s.hex()))
+    with open(stem + ".wtns", "w") as f:
+        f.write("W0 = 0x%s\n" % w0.hex())
+    return depth * 1944 + 972

@@ -74,3 +74,25 @@ def test_prover_then_verifier(ctx, tmp_path, name):
     lines[0], lines[-1] = lines[0].split(" = ")[0] + " = " + lines[-1].split(" = ")[1], lines[-1].split(" = ")[0] + " = " + lines[0].split(" = ")[1]
     (tmp_path / (name + ".coms")).write_text("".join(lines))
     assert not cli.verifier(stem, ctx=ctx, quiet=True)
+
+
+@pytest.mark.gpu
+def test_depth20_merkle_path_cfg4b(ctx, tmp_path):
+    """SURVEY.md section 8 cfg 4b: BASELINE.json's "depth 20" wording read literally - one authentication path through the CLI."""
+    from bulletproofs_gadgets_amd import workloads
+    stem = str(tmp_path / "path20")
+    n = workloads.merkle_path_files(stem, depth=20)
+    assert n == 39852
+    p, proof = cli.prover(stem, ctx=ctx, seed=b"cfg4b", rng_seed=bytes(32), quiet=True)
+    assert p.get_num_multiplications() == n and p.num_committed() == 4 and len(proof) == 1536
+    assert p.num_constraints() == 20 * 3888 + 1 + 1946          # 2 per multiplier, the root equality, the leaf image equality x2
+    assert cli.verifier(stem, ctx=ctx, quiet=True)
+    v, tv = cli.assemble_verifier(stem)
+    vi = v.instance()
+    oc = O.FlatCircuit(vi.n, vi.m, None, None, None, vi.row_ptr, vi.term_var, vi.term_coef, vi.coef)
+    assert O.verify(O.Gens(65536), tv.state, oc, vi.commitments, proof) == 0
+    # a wrong sibling must make the prover's own circuit unsatisfied -> the proof does not verify
+    lines = open(stem + ".inst").read().splitlines()
+    lines[7] = lines[7][:-2] + ("00" if lines[7][-2:] != "00" else "01")
+    open(stem + ".inst", "w").write("\n".join(lines) + "\n")
+    assert not cli.verifier(stem, ctx=ctx, quiet=True)
