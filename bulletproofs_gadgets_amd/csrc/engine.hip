@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include "engine.hpp"
 #include "hip/kernels.cuh"
@@ -17,6 +18,7 @@ namespace bpg {
 // launch on the engine stream, bracketed by HIP events when the profile asks for this kernel
 #define BPG_LAUNCH_ID(I, id, kernel, grid, block, ...) do { (I).prof_begin(id); hipLaunchKernelGGL(kernel, grid, block, 0, (I).st, __VA_ARGS__); (I).prof_end(id); } while (0)
 #define BPG_LAUNCH(I, kernel, grid, block, ...) BPG_LAUNCH_ID(I, KID_##kernel, kernel, grid, block, __VA_ARGS__)
+#define BPG_LAUNCH_LDS(I, id, kernel, grid, block, lds, ...) do { (I).prof_begin(id); hipLaunchKernelGGL(kernel, grid, block, lds, (I).st, __VA_ARGS__); (I).prof_end(id); } while (0)
 
 namespace {
 
@@ -85,8 +87,9 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_digits_count) X(k_msm_digits_scatter) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul)
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -123,10 +126,14 @@ struct Engine::Impl {
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist;
+    uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
+    // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
+    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial;
+    uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
     PinBuf h_raw, h_small;
     uint64_t gens_cap = 0;
 
@@ -142,6 +149,8 @@ Engine::Engine(int device) : device_(device) {
     impl_ = new Impl();
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
+    if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
@@ -160,7 +169,8 @@ Engine::~Engine() {
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch};
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
+                      &impl_->tile_hist, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release();
     (void)hipStreamDestroy(impl_->st);
@@ -298,27 +308,50 @@ void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, u
 // ------------------------------------------------------------------------------------------------ MSM pipeline
 void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     const uint32_t total = S.start[S.nseg];
-    uint32_t per = total / (nmsm ? nmsm : 1); if (per < 1) per = 1;
-    int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > 16) cc = 16;
+    if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
+    uint32_t per = total / nmsm; if (per < 1) per = 1;
+    int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > (int)msm_cmax) cc = (int)msm_cmax;
     // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
     const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
     const uint32_t nkeys = nmsm * W * nb;
     const uint32_t seg = nb < 32 ? nb : 32, nsegpw = nb / seg;
     const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
+    // tiling plan: the segments of one MSM are contiguous; tiles never span two MSMs
+    MsmPlan P; std::memset(&P, 0, sizeof P);
+    P.nmsm = nmsm; P.W = W; P.nb = nb;
+    {
+        uint32_t lg = ceil_log2(per) > 6 ? ceil_log2(per) - 6 : 0; if (lg < 10) lg = 10; if (lg > 14) lg = 14;
+        P.lgTile = lg;
+        uint32_t k = 0;
+        for (uint32_t m = 0; m < nmsm; m++) {
+            P.term_start[m] = k < S.nseg ? S.start[k] : total;
+            while (k < S.nseg && S.msm[k] == m) k++;
+        }
+        if (k != S.nseg) throw std::logic_error("msm: segments must be grouped by result in ascending order");
+        P.term_start[nmsm] = total;
+        for (uint32_t m = 0; m < nmsm; m++) {
+            const uint32_t nt = cdiv(P.term_start[m + 1] - P.term_start[m], 1u << lg);
+            P.tile_start[m + 1] = P.tile_start[m] + nt; if (nt > P.tmax) P.tmax = nt;
+        }
+        for (uint32_t j = 0; j < W; j++) { const uint32_t bit = ((j + 1) * 254u) / W - 1; P.bias[bit >> 5] |= 1u << (bit & 31); }
+    }
+    const uint32_t ntiles = P.tile_start[nmsm];
     counts.ensure((size_t)(nkeys + 1) * 4); starts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
     blocksum.ensure((size_t)(nblocks + 1) * 4);
     entries.ensure((size_t)(total ? total : 1) * W * 4);
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
-    HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)(nkeys + 1) * 4, st));
-    if (total) BPG_LAUNCH_ID((*this), KID_k_msm_digits_count, k_msm_digits<0>, dim3(cdiv(total, 256)), dim3(256), S, total, W, nb, counts.as<uint32_t>(), (uint32_t *)nullptr);
+    tile_hist.ensure((size_t)nmsm * W * (P.tmax ? P.tmax : 1) * nb * 4);
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys);
     BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
     BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-    if (total) BPG_LAUNCH_ID((*this), KID_k_msm_digits_scatter, k_msm_digits<1>, dim3(cdiv(total, 256)), dim3(256), S, total, W, nb, cursor.as<uint32_t>(), entries.as<uint32_t>());
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     {   // balanced sweep: chunk size 2^lgCH entries per thread, between 32 and 256 depending on the list length
         const uint64_t M = (uint64_t)total * W;                 // upper bound of the entry count (zero digits are skipped)
         uint32_t lgCH = 5; while (lgCH < 8 && (M >> lgCH) > 131072) lgCH++;
+        if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 3 && v <= 10 && M > (1u << 20)) lgCH = (uint32_t)v; }
         const uint32_t nchunks = cdiv(M ? M : 1, 1u << lgCH);
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
@@ -587,9 +620,53 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const ge_niels *Gst = Gtab, *Hst = Htab;
     const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
     uint64_t mcur = N;
+    // table-driven tail state (kernels.cuh "table-driven IPA tail")
+    bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv;
     for (uint32_t round = 0; round < lgN; round++) {
         const uint64_t h = mcur / 2;
         const bool first = round == 0;
+        if (!tt_on && I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) {
+            // freeze the generators at this level: window tables for G[0..M0), H[0..M0) and B
+            tt_on = true; tt_lgM0 = ceil_log2(mcur); tt_j = 0; tt_cur = 0;
+            const uint32_t M0 = (uint32_t)mcur, npts = 2 * M0 + 1;
+            I.tt_bases.ensure((size_t)npts * TT_WINDOWS * sizeof(ge_ext));
+            I.tt_table.ensure((size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
+            I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
+            I.tt_partial.ensure((size_t)2 * cdiv((uint64_t)M0 * 8, 256) * sizeof(ge_ext));
+            BPG_LAUNCH(I, k_tt_bases, dim3(cdiv(npts, 256)), dim3(256), Gst, Hst, Bn, I.tt_bases.as<ge_ext>(), M0);
+            BPG_LAUNCH(I, k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), I.tt_bases.as<ge_ext>(), I.tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
+            BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
+                       I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
+        }
+        if (tt_on) {
+            const uint32_t M0 = 1u << tt_lgM0;
+            scm *c0 = I.tt_c.as<scm>() + (size_t)tt_cur * 2 * M0, *c1 = I.tt_c.as<scm>() + (size_t)(tt_cur ^ 1u) * 2 * M0;
+            if (tt_j > 0) {     // apply the previous round's challenge: fold a, b (2*mcur -> mcur) and double the coefficient tables
+                BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(mcur, 1ull << (tt_j - 1)), 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)mcur,
+                           c0, c1, 1u << (tt_j - 1), M0);
+                tt_cur ^= 1u; std::swap(c0, c1);
+            }
+            const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
+            BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
+                       I.tt_partial.as<ge_ext>());
+            BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
+                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.comp.as<uint8_t>());
+            HIPCHK(hipGetLastError());
+            uint8_t lr[64];
+            HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            lap(tm ? &tm->ipa_msm : nullptr);
+            T.append_point("L", lr); T.append_point("R", lr + 32);
+            proof.insert(proof.end(), lr, lr + 64);
+            tt_u = T.challenge_scalar("u"); tt_uinv = tt_u.invert();
+            tt_j++;
+            mcur = h;
+            if (round + 1 == lgN) {   // last round: only the scalar fold remains
+                BPG_LAUNCH(I, k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)h);
+                HIPCHK(hipGetLastError());
+            }
+            continue;
+        }
         scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + h, *sRG = sLH + h, *sRH = sRG + h;
         const uint32_t blocks = std::min<uint32_t>(cdiv(h, 256), 1024);
         I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);

@@ -73,6 +73,24 @@ BPG_HD ge_ext ge_dbl_noT(const ge_ext &p) {
     return r;
 }
 
+// projective Niels operand (Y+X, Y-X, Z, 2dT; 128 bytes): table entries that are never normalised (IPA tail tables)
+struct ge_pniels { fe ypx, ymx, Z, t2d; };
+BPG_HD ge_pniels ge_to_pniels(const ge_ext &p) {
+    ge_pniels r; r.ypx = fe_add(p.Y, p.X); r.ymx = fe_sub(p.Y, p.X); r.Z = p.Z; r.t2d = fe_mul(p.T, FE_D2());
+    return r;
+}
+// extended + projective Niels, 8M; neg in {0,1} subtracts instead (operand swap, no divergence)
+BPG_HD ge_ext ge_add_pniels_signed(const ge_ext &p, const ge_pniels &q, uint32_t neg) {
+    fe qp = fe_select(q.ypx, q.ymx, neg), qm = fe_select(q.ymx, q.ypx, neg), qt = fe_cneg(q.t2d, neg);
+    fe A = fe_mul(fe_sub(p.Y, p.X), qm);
+    fe B = fe_mul(fe_add(p.Y, p.X), qp);
+    fe C = fe_mul(p.T, qt);
+    fe D = fe_mul(p.Z, q.Z); D = fe_add(D, D);
+    fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    ge_ext r; r.X = fe_mul(E, F); r.Y = fe_mul(G, H); r.T = fe_mul(E, H); r.Z = fe_mul(F, G);
+    return r;
+}
+
 // extended -> affine Niels given 1/Z
 BPG_HD ge_niels ge_to_niels(const ge_ext &p, const fe &zinv) {
     fe x = fe_mul(p.X, zinv), y = fe_mul(p.Y, zinv);

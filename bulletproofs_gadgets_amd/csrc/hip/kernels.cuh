@@ -316,6 +316,145 @@ __global__ void __launch_bounds__(256) k_ipa_fold_scalars(scm *__restrict__ a, s
     b[i] = sc_add(sc_mont_mul(b[i], uinv), sc_mont_mul(u, b[h + i]));
 }
 
+// ------------------------------------------------------------------------------------------------ table-driven IPA tail
+// Once a round is down to M0 generators per side (M0 = 2^14 by default) the remaining lg M0 rounds are latency-bound:
+// a generator fold is 253 dependent doublings (about 1.15 ms on one wave however few points there are) and the
+// bucket-method MSM ends in another ~250.  Instead the generators are frozen at that level and every later L_k, R_k is
+// computed over the SAME 2*M0 base points with expanded scalars (the verifier's s-vector idea): with challenges u_1..u_j
+// drawn since the freeze, the virtual folded generator i' of size M_j = M0 / 2^j is
+//     G^(j)[i'] = Gamma_0 * sum_t prod_k (bit_k(t) ? u_k : u_k^-1) * gf(p) * Gst[p],      p = i' + t*M_j
+//     H^(j)[i'] = Eta_0   * sum_t prod_k (bit_k(t) ? u_k^-1 : u_k) * y^-p * gf(p) * Hst[p]
+// (bit_k(t) = bit j-k of t; the y^-M_k factors of the H fold scalars collapse into y^-p).  Each base point then carries
+// exactly one scalar per round and lands in exactly one of L_k / R_k.  A one-off table of k * 2^(4w) * P for every base
+// point (w < 64 windows, k = 1..8, projective Niels, 64 KB per point) turns each of those scalar multiplications into 64
+// table additions and no doubling at all; 8 threads share a point, partial sums go through an LDS tree.
+#define TT_WINDOWS 64
+#define TT_MULTS 8
+
+// bases[p * 64 + w] = 2^(4w) * P_p for the 2*M0 + 1 base points G[0..M0), H[0..M0), B  (the only 252-doubling chain of the tail)
+__global__ void __launch_bounds__(256) k_tt_bases(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, const ge_niels *__restrict__ B,
+                                                  ge_ext *__restrict__ bases, uint32_t M0) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 2 * M0 + 1) return;
+    const ge_niels q = p < M0 ? G[p] : (p < 2 * M0 ? H[p - M0] : B[0]);
+    ge_ext cur = ge_madd(ge_identity(), q);
+    ge_ext *dst = bases + (size_t)p * TT_WINDOWS;
+    for (uint32_t w = 0; w < TT_WINDOWS; w++) {
+        dst[w] = cur;
+        if (w + 1 < TT_WINDOWS) { cur = ge_dbl(cur); cur = ge_dbl(cur); cur = ge_dbl(cur); cur = ge_dbl(cur); }
+    }
+}
+// table[i * 8 + k] = (k + 1) * bases[i], i = p * 64 + w
+__global__ void __launch_bounds__(256) k_tt_multiples(const ge_ext *__restrict__ bases, ge_pniels *__restrict__ table, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_pniels *dst = table + (size_t)i * TT_MULTS;
+    const ge_ext b1 = bases[i];
+    const ge_pniels n1 = ge_to_pniels(b1);
+    dst[0] = n1;
+    const ge_ext b2 = ge_dbl(b1); dst[1] = ge_to_pniels(b2);
+    const ge_ext b3 = ge_add_pniels_signed(b2, n1, 0); dst[2] = ge_to_pniels(b3);
+    const ge_ext b4 = ge_dbl(b2); dst[3] = ge_to_pniels(b4);
+    const ge_ext b5 = ge_add_pniels_signed(b4, n1, 0); dst[4] = ge_to_pniels(b5);
+    const ge_ext b6 = ge_dbl(b3); dst[5] = ge_to_pniels(b6);
+    const ge_ext b7 = ge_add_pniels_signed(b6, n1, 0); dst[6] = ge_to_pniels(b7);
+    const ge_ext b8 = ge_dbl(b4); dst[7] = ge_to_pniels(b8);
+}
+// per-base-point constant factors: fG[p] = gf(p), fH[p] = y^-p * gf(p); c tables start as {Gamma_0}, {Eta_0}
+__global__ void __launch_bounds__(256) k_tt_factors(const scm *__restrict__ yinvpow, scm u_ch, uint32_t first_round, uint32_t n, uint32_t M0,
+                                                    scm Gamma0, scm Eta0, scm *__restrict__ fG, scm *__restrict__ fH, scm *__restrict__ c0) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) { c0[0] = Gamma0; c0[M0] = Eta0; }
+    if (p >= M0) return;
+    const bool pad = first_round && p >= n;
+    fG[p] = pad ? u_ch : SC_R1();
+    fH[p] = pad ? sc_mont_mul(yinvpow[p], u_ch) : yinvpow[p];
+}
+// after challenge u: fold the scalar vectors (2h -> h) and extend the coefficient tables (cnt -> 2*cnt entries per side)
+__global__ void __launch_bounds__(256) k_tt_advance(scm *__restrict__ a, scm *__restrict__ b, scm u, scm uinv, uint32_t h,
+                                                    const scm *__restrict__ cprev, scm *__restrict__ cnext, uint32_t cnt, uint32_t M0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < h) {
+        a[i] = sc_add(sc_mont_mul(a[i], u), sc_mont_mul(uinv, a[h + i]));
+        b[i] = sc_add(sc_mont_mul(b[i], uinv), sc_mont_mul(u, b[h + i]));
+    }
+    if (i < cnt) {
+        const scm g = cprev[i], e = cprev[M0 + i];
+        cnext[2 * i] = sc_mont_mul(g, uinv); cnext[2 * i + 1] = sc_mont_mul(g, u);
+        cnext[M0 + 2 * i] = sc_mont_mul(e, u); cnext[M0 + 2 * i + 1] = sc_mont_mul(e, uinv);
+    }
+}
+// signed 4-bit digits without a carry chain: nibble w of (s + 0x88..8) minus 8 lies in [-8, 7]
+__device__ __forceinline__ void tt_biased_words(uint32_t w[8], const scm &s) {
+    sc_to_words(w, s);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + 0x88888888ull + carry; w[k] = (uint32_t)t; carry = t >> 32; }
+}
+// sub-round j of the tail (h = M0 >> (j+1)): blockIdx.y = 0 accumulates L, 1 accumulates R; thread = (base point, 8 windows)
+__global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ table, const scm *__restrict__ a, const scm *__restrict__ b,
+                                                  const scm *__restrict__ fG, const scm *__restrict__ fH, const scm *__restrict__ c,
+                                                  uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */) {
+    __shared__ ge_ext lds[256];
+    const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M0 = 1u << lgM0, e = tid >> 3, g = tid & 7u;
+    ge_ext acc = ge_identity();
+    if (e < M0) {
+        const bool isH = e >= (M0 >> 1);
+        const uint32_t e2 = isH ? e - (M0 >> 1) : e;
+        const uint32_t lgh = lgM0 - j - 1, h = 1u << lgh;
+        const uint32_t t = e2 >> lgh, i = e2 & (h - 1);
+        const bool hi = (cls == 0) != isH;                         // L: G_hi and H_lo;  R: G_lo and H_hi
+        const uint32_t p = (t << (lgh + 1)) | (hi ? h : 0u) | i;
+        const uint32_t sidx = hi ? i : (h | i);                    // the scalar of the opposite half
+        scm s = isH ? b[sidx] : a[sidx];
+        s = sc_mont_mul(s, isH ? fH[p] : fG[p]);
+        s = sc_mont_mul(s, c[(isH ? M0 : 0u) + t]);
+        uint32_t w[8]; tt_biased_words(w, s);
+        const ge_pniels *tbl = table + ((size_t)(isH ? M0 : 0u) + p) * (TT_WINDOWS * TT_MULTS) + (size_t)g * 8 * TT_MULTS;
+        const uint32_t word = w[g];
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; k++) {
+            const int32_t d = (int32_t)((word >> (4 * k)) & 15u) - 8;
+            if (d == 0) continue;
+            const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
+        }
+    }
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+}
+// block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>, compress
+__global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ a, const scm *__restrict__ b,
+                                                   uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, uint8_t *__restrict__ out) {
+    __shared__ ge_ext lds[256];
+    __shared__ scm slds[256];
+    const uint32_t cls = blockIdx.x;
+    scm ip = sc_zero();
+    for (uint32_t i = threadIdx.x; i < h; i += 256) ip = sc_add(ip, cls == 0 ? sc_mont_mul(a[i], b[h + i]) : sc_mont_mul(a[h + i], b[i]));
+    const scm cw = sc_mont_mul(block_sum_256(ip, slds), wq);
+    ge_ext acc = ge_identity();
+    for (uint32_t s = threadIdx.x; s < nblk; s += 256) acc = ge_add(acc, partial[cls * nblk + s]);
+    if (threadIdx.x < TT_WINDOWS) {
+        uint32_t w[8]; tt_biased_words(w, cw);
+        const int32_t d = (int32_t)((w[threadIdx.x >> 3] >> (4 * (threadIdx.x & 7u))) & 15u) - 8;
+        if (d != 0) {
+            const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            acc = ge_add_pniels_signed(acc, tableB[threadIdx.x * TT_MULTS + mag - 1], neg);
+        }
+    }
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ge_compress(out + 32 * cls, lds[0]);
+}
+
 // Generator fold with a wave-uniform scalar: out[i] = P_i + s * Q_i, P_i = tab[i], Q_i = tab[h + i].
 // naf[k] in {-1,0,1} is the non-adjacent form of s (shared by every lane, so the add/skip branch never diverges).
 // Threads [0,h) fold G with nafG{A,B}, threads [h,2h) fold H with nafH{A,B}; class B applies to i >= split (first round only).
@@ -413,24 +552,71 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
     return s;
 }
 
-// pass 0: histogram (counts[key]++), pass 1: scatter entries to cursor[key]++.
-// key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment
+// Sorting the (term, window) entries by bucket without global atomics (device-scope atomics on MI355X resolve beyond the
+// per-XCD L2 and were the slowest part of the MSM): the terms of each MSM are cut into tiles of 2^lgTile terms; block
+// (tile, window) histograms its tile in LDS (LDS atomics) and writes the row H[msm*W+window][tile][0..nb) with plain coalesced
+// stores; k_msm_tile_prefix turns the rows of one key column into exclusive prefixes over the tiles and emits the bucket
+// totals; after the usual scan of the totals, block (tile, window) reloads its row (+ bucket start) into LDS as cursors and
+// scatters its entries.  key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment.
+// Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
+// field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
+struct MsmPlan {
+    uint32_t nmsm, W, nb, lgTile, tmax;
+    uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
+    uint32_t tile_start[5];      // first tile of MSM m
+    uint32_t bias[8];
+};
+__device__ __forceinline__ int32_t msm_digit_biased(const uint32_t w[8], uint32_t W, uint32_t win) {
+    const uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
+    const uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+    return (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
+}
+__device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, const MsmPlan &P) {
+    sc_to_words(w, sc);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + P.bias[k] + carry; w[k] = (uint32_t)t; carry = t >> 32; }
+}
 template <int PASS>
-__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, uint32_t total, uint32_t W, uint32_t nb,
-                                                    uint32_t *__restrict__ counts_or_cursor, uint32_t *__restrict__ entries) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-    uint32_t w[8]; sc_to_words(w, S.sc[s][i]);
-    uint32_t carry = 0, base = S.msm[s] * W;
-    for (uint32_t win = 0; win < W; win++) {
-        int32_t d = msm_digit(w, W, win, carry);
+__global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, uint32_t *__restrict__ H, const uint32_t *__restrict__ starts,
+                                                  uint32_t *__restrict__ entries) {
+    extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
+    const uint32_t T = blockIdx.x, win = blockIdx.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 4; k++) if (k < P.nmsm && T >= P.tile_start[k]) m = k;
+    const uint32_t t = T - P.tile_start[m];
+    const uint32_t g0 = P.term_start[m] + (t << P.lgTile);
+    const uint32_t g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
+    const uint32_t mw = m * P.W + win;
+    uint32_t *row = H + ((size_t)mw * P.tmax + t) * P.nb;
+    if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = 0;
+    else for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
+    __syncthreads();
+    for (uint32_t g = g0 + threadIdx.x; g < g1; g += 256) {
+        const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+        uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
+        const int32_t d = msm_digit_biased(w, P.W, win);
         if (d == 0) continue;
-        uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-        uint32_t key = (base + win) * nb + (mag - 1);
-        if (PASS == 0) atomicAdd(&counts_or_cursor[key], 1u);
-        else { uint32_t pos = atomicAdd(&counts_or_cursor[key], 1u); entries[pos] = (neg << 31) | (s << 27) | i; }
+        const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+        if (PASS == 0) atomicAdd(&tile_lds[mag - 1], 1u);
+        else { const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i; }
     }
+    if (PASS == 0) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < P.nb; b += 256) row[b] = tile_lds[b];
+    }
+}
+// one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
+__global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys) {
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key >= nkeys) return;
+    const uint32_t mw = key / P.nb, b = key - mw * P.nb, m = mw / P.W;
+    const uint32_t nt = P.tile_start[m + 1] - P.tile_start[m];
+    uint32_t *col = H + (size_t)mw * P.tmax * P.nb + b;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < nt; t++) { const uint32_t v = col[(size_t)t * P.nb]; col[(size_t)t * P.nb] = run; run += v; }
+    counts[key] = run;
 }
 
 // exclusive scan of counts[0..nkeys) in three launches (chunk = 2048 keys per block)
@@ -476,6 +662,12 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 // padding terms of the first IPA round, repeated witness values, range-proof bits) is spread over many threads instead of
 // serialising one.  A bucket that lies inside one chunk is stored directly; a bucket that crosses chunk boundaries leaves
 // one partial per chunk (slotA = piece at the chunk's beginning, slotB = piece at its end) for k_bucket_combine.
+// bucket that holds sorted entry e: the k >= klo with starts[k] <= e < starts[k+1]  (upper_bound - 1)
+__device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ starts, uint32_t nkeys, uint32_t e, uint32_t klo) {
+    uint32_t lo = klo, hi = nkeys + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
 __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
                                                        ge_ext *__restrict__ buckets, ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB,
                                                        uint32_t nkeys, uint32_t lgCH) {
@@ -484,16 +676,18 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
     const uint32_t M = starts[nkeys];                      // true entry count (zero digits were skipped)
     if (e0 >= M) return;
     const uint32_t e1 = (e0 + (1u << lgCH) < M) ? e0 + (1u << lgCH) : M;
-    uint32_t lo = 0, hi = nkeys + 1;                       // upper_bound(starts, e0) - 1 = bucket of entry e0
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e0) lo = mid + 1; else hi = mid; }
-    uint32_t k = lo - 1, kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
+    uint32_t k = msm_bucket_of(starts, nkeys, e0, 0), kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
     ge_ext acc = ge_identity();
     for (uint32_t e = e0; e < e1; e++) {
         if (e >= kend) {
             if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
             else { if (seg_begin == e0) slotA[c] = acc; /* a piece ending inside the chunk cannot also end it */ }
             acc = ge_identity(); seg_begin = e;
-            do { k++; kstart = kend; kend = starts[k + 1]; } while (e >= kend);
+            k++; kstart = kend; kend = starts[k + 1];
+            if (e >= kend) {                                 // a run of empty buckets (half of a 15-bit window is structurally
+                k = msm_bucket_of(starts, nkeys, e, k + 1);  // empty): search instead of walking it with dependent loads
+                kstart = starts[k]; kend = starts[k + 1];
+            }
         }
         const uint32_t ent = entries[e];
         const ge_niels q = S.pts[(ent >> 27) & 7u][ent & 0x07ffffffu];
