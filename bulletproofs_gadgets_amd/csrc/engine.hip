@@ -88,7 +88,7 @@ struct DeviceCircuit {
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish)
 enum KernelId {
 #define X(n) KID_##n,
@@ -126,13 +126,15 @@ struct Engine::Impl {
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy;
     uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
-    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial;
+    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c;
+    PinBuf h_naf;
+    uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
     PinBuf h_raw, h_small;
     uint64_t gens_cap = 0;
@@ -150,6 +152,7 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
@@ -170,9 +173,9 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c};
     for (DevBuf *b : bufs) b->release();
-    impl_->h_raw.release(); impl_->h_small.release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release();
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
 }
@@ -342,23 +345,25 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
     tile_hist.ensure((size_t)nmsm * W * (P.tmax ? P.tmax : 1) * nb * 4);
+    uint32_t lgCH = 5;                                          // balanced sweep: 2^lgCH sorted entries per thread
+    if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 3 && v <= 10) lgCH = (uint32_t)v; }
+    const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
+    const uint32_t nchunks = cdiv(Mub ? Mub : 1, 1u << lgCH);
+    heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
     if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
-    BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys);
+    BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
     BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
     if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
-    {   // balanced sweep: chunk size 2^lgCH entries per thread, between 32 and 256 depending on the list length
-        const uint64_t M = (uint64_t)total * W;                 // upper bound of the entry count (zero digits are skipped)
-        uint32_t lgCH = 5; while (lgCH < 8 && (M >> lgCH) > 131072) lgCH++;
-        if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 3 && v <= 10 && M > (1u << 20)) lgCH = (uint32_t)v; }
-        const uint32_t nchunks = cdiv(M ? M : 1, 1u << lgCH);
+    {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
         BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(), buckets.as<ge_ext>(),
                    slotA, slotB, nkeys, lgCH);
-        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH);
+        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH, heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, lgCH, heavy.as<uint32_t>());
     }
     const uint32_t nred = nmsm * W * nsegpw;
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
@@ -369,11 +374,11 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
 }
 
 namespace {
-void seg_push(MsmSegs &S, const scm *sc, const ge_niels *pts, uint32_t len, uint32_t msm) {
+void seg_push(MsmSegs &S, const scm *sc, const ge_niels *pts, uint32_t len, uint32_t msm, uint32_t lgblk = 31) {
     if (!len) return;
     if (S.nseg >= BPG_MAX_SEGS) throw std::logic_error("too many MSM segments");
     uint32_t k = S.nseg++;
-    S.sc[k] = sc; S.pts[k] = pts; S.len[k] = len; S.msm[k] = msm;
+    S.sc[k] = sc; S.pts[k] = pts; S.len[k] = len; S.msm[k] = msm; S.lgblk[k] = lgblk;
     S.start[k + 1] = S.start[k] + len;
 }
 MsmSegs seg_new() { MsmSegs S; std::memset(&S, 0, sizeof S); return S; }
@@ -614,7 +619,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         I.ipa_s.ensure(4 * half * sizeof(scm));
         I.ipa_tabA.ensure(2 * half * sizeof(ge_niels)); I.ipa_tabB.ensure((half > 1 ? half : 2) * sizeof(ge_niels));
         I.scratch_ext.ensure(2 * half * sizeof(ge_ext));
-        I.naf.ensure(sizeof(FoldNaf));
+        I.naf.ensure(4096);
     }
     Scalar Gamma = Scalar::one(), Eta = Scalar::one();
     const ge_niels *Gst = Gtab, *Hst = Htab;
@@ -622,6 +627,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     uint64_t mcur = N;
     // table-driven tail state (kernels.cuh "table-driven IPA tail")
     bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv;
+    // grouped-fold state
+    const uint32_t GRP_STRIDE = 64;
+    uint32_t g_j = 0, g_r = 1, g_cur = 0, g_index = 0; uint64_t g_M = N; bool g_first = true; std::vector<Scalar> g_us;
     for (uint32_t round = 0; round < lgN; round++) {
         const uint64_t h = mcur / 2;
         const bool first = round == 0;
@@ -667,20 +675,35 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             }
             continue;
         }
-        scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + h, *sRG = sLH + h, *sRH = sRG + h;
-        const uint32_t blocks = std::min<uint32_t>(cdiv(h, 256), 1024);
+        // ---- grouped fold rounds (kernels.cuh k_ipa_prep / k_fold_points): sub-round g_j of a group of g_r rounds on tables of size g_M
+        if (g_j == 0) {
+            g_M = mcur; g_first = first;
+            uint32_t left = ceil_log2(mcur);                               // rounds until the tables would be a single point
+            if (I.tt_lg > 0 && left > I.tt_lg) left -= I.tt_lg;            // ... or until the tail freezes them
+            g_r = std::min<uint32_t>(I.fold_group, left);
+            g_us.clear();
+            I.grp_c.ensure(4 * GRP_STRIDE * sizeof(scm));
+            g_cur = 0;
+            hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, st, I.grp_c.as<scm>(), (uint32_t)GRP_STRIDE, to_scm(Gamma), to_scm(Eta));
+        }
+        scm *c0 = I.grp_c.as<scm>() + (size_t)g_cur * 2 * GRP_STRIDE;
+        const uint64_t cnt = g_M / 2;                                       // expanded scalars per side: h * 2^g_j
+        scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + cnt, *sRG = sLH + cnt, *sRH = sRG + cnt;
+        const uint32_t blocks = std::min<uint32_t>(cdiv(cnt, 256), 1024);
+        const uint32_t lgh = ceil_log2(h);
         I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
-        BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), to_scm(Gamma), to_scm(Eta), uch_m,
-                           (uint32_t)first, (uint32_t)n, (uint32_t)h, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
+        BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), c0, c0 + GRP_STRIDE, uch_m,
+                           (uint32_t)g_first, (uint32_t)n, lgh, g_j, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
         BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
         BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
         {
             MsmSegs S = seg_new();
-            seg_push(S, sLG, Gst + h, (uint32_t)h, 0);
-            seg_push(S, sLH, Hst, (uint32_t)h, 0);
+            const uint32_t lgblk = g_j ? lgh : 31u;                         // every other block of h points of the group-start tables
+            seg_push(S, sLG, Gst + h, (uint32_t)cnt, 0, lgblk);
+            seg_push(S, sLH, Hst, (uint32_t)cnt, 0, lgblk);
             seg_push(S, I.extras.as<scm>() + 3, Bn, 1, 0);
-            seg_push(S, sRG, Gst, (uint32_t)h, 1);
-            seg_push(S, sRH, Hst + h, (uint32_t)h, 1);
+            seg_push(S, sRG, Gst, (uint32_t)cnt, 1, lgblk);
+            seg_push(S, sRH, Hst + h, (uint32_t)cnt, 1, lgblk);
             seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
             I.msm(S, 2, I.msm_result.as<ge_ext>());
         }
@@ -693,38 +716,57 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         T.append_point("L", lr); T.append_point("R", lr + 32);
         proof.insert(proof.end(), lr, lr + 64);
         const Scalar u = T.challenge_scalar("u"), uinv = u.invert();
-        BPG_LAUNCH(I, k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), a, b, to_scm(u), to_scm(uinv), (uint32_t)h);
-        if (h > 1 || true) {
-            // generator fold: Gst'[i] = Gst[i] + sG * Gst[h+i],  Hst'[i] = Hst[i] + sH * Hst[h+i]
-            const Scalar sGA = u * u, sHA = uinv * uinv * yinv_pow2[ceil_log2(h)];
-            int8_t dg[4][256]; int32_t tops[4];
-            tops[0] = naf256(sGA, dg[0]);
-            tops[2] = naf256(sHA, dg[2]);
-            if (first) { tops[1] = naf256(sGA * u_ch, dg[1]); tops[3] = naf256(sHA * u_ch, dg[3]); }
-            else { std::memcpy(dg[1], dg[0], 256); tops[1] = tops[0]; std::memcpy(dg[3], dg[2], 256); tops[3] = tops[2]; }
-            FoldNaf fn; std::memset(&fn, 0, sizeof fn);
-            for (int cls = 0; cls < 4; cls++) {
-                fn.top[cls] = tops[cls];
-                for (int k = 0; k < 256; k++) { if (dg[cls][k]) fn.nz[cls][k >> 5] |= 1u << (k & 31); if (dg[cls][k] < 0) fn.neg[cls][k >> 5] |= 1u << (k & 31); }
-            }
-            const uint32_t split = first ? (uint32_t)(n - h) : (uint32_t)h;
-            ge_niels *dst = (round & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * h, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), fn, (uint32_t)h, split);
-            {   // bookkeeping for the roofline: 4h points read + 2h written at 32 B (information content) resp. 96/128 B (device formats);
-                // field multiplications: 8 per doubling, 7 per mixed addition
-                double fm = 0;
-                for (int cls = 0; cls < 4; cls++) {
-                    int adds = 0; for (int k = 0; k <= tops[cls]; k++) adds += dg[cls][k] != 0;
-                    const double lanes = (cls & 1) ? (double)(h - split) : (double)split;
-                    fm += lanes * (8.0 * (tops[cls] + 1) + 7.0 * adds + 7.0);
-                }
-                I.prof_note(KID_k_fold_points, 32.0 * 6 * h, 96.0 * 4 * h + 128.0 * 2 * h, fm);
-            }
-            BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * h, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, (uint32_t)(2 * h));
-            HIPCHK(hipGetLastError());
-            Gst = dst; Hst = dst + h;
+        g_us.push_back(u);
+        {   // fold a, b and extend the coefficient tables cG, cH (2^g_j -> 2^(g_j+1) entries)
+            scm *c1 = I.grp_c.as<scm>() + (size_t)(g_cur ^ 1u) * 2 * GRP_STRIDE;
+            BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(h, 1ull << g_j), 256)), dim3(256), a, b, to_scm(u), to_scm(uinv), (uint32_t)h,
+                       c0, c1, 1u << g_j, (uint32_t)GRP_STRIDE);
+            g_cur ^= 1u;
         }
-        Gamma = uinv * Gamma; Eta = u * Eta;
+        g_j++;
+        if (g_j == g_r) {
+            // generator fold of the whole group: Gst'[i] = Gst[i] + sum_{t>=1} sG_t Gst[i + t*Mr], same for H, with
+            // sG_t = prod_k (u_k^2)^bit_k(t), sH_t = prod_k (u_k^-2 y^-(g_M/2^k))^bit_k(t), bit_k(t) = bit (g_r - k) of t
+            const uint32_t Mr = (uint32_t)(g_M >> g_r), nterms = (1u << g_r) - 1u;
+            std::vector<Scalar> fG(g_r), fH(g_r);
+            for (uint32_t k = 1; k <= g_r; k++) {
+                const Scalar &uk = g_us[k - 1]; const Scalar ukinv = uk.invert();
+                fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
+            }
+            I.h_naf.ensure((size_t)4 * nterms * 16 * 4); I.naf.ensure((size_t)4 * nterms * 16 * 4);
+            uint32_t *hn = I.h_naf.as<uint32_t>();
+            std::memset(hn, 0, (size_t)4 * nterms * 16 * 4);
+            int32_t top = -1; double adds_fm = 0;
+            for (uint32_t q = 0; q < nterms; q++) {
+                const uint32_t t = q + 1;
+                Scalar sg = Scalar::one(), sh = Scalar::one();
+                for (uint32_t k = 1; k <= g_r; k++) if ((t >> (g_r - k)) & 1u) { sg = sg * fG[k - 1]; sh = sh * fH[k - 1]; }
+                const Scalar cls_s[4] = {sg, sg * u_ch, sh, sh * u_ch};
+                // lanes of term t that are padding generators (first group): i + t*Mr >= n
+                const uint64_t lo = (uint64_t)t * Mr, nB = !g_first ? 0 : (lo >= n ? Mr : (lo + Mr > n ? lo + Mr - n : 0));
+                for (int cls = 0; cls < 4; cls++) {
+                    if ((cls & 1) && !g_first) continue;
+                    int8_t dg[256]; const int32_t tp = naf256(cls_s[cls], dg);
+                    if (tp > top) top = tp;
+                    uint32_t *d = hn + ((size_t)cls * nterms + q) * 16; int adds = 0;
+                    for (int k = 0; k < 256; k++) { if (dg[k]) { d[k >> 5] |= 1u << (k & 31); adds++; } if (dg[k] < 0) d[8 + (k >> 5)] |= 1u << (k & 31); }
+                    adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
+                }
+            }
+            HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
+            FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
+            ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * Mr, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<uint32_t>(), fg);
+            // bookkeeping for the roofline: 2*g_M points read + 2*Mr written at 32 B (information content) resp. 96/128 B (device formats);
+            // field multiplications: 8 per doubling, 7 per mixed addition
+            I.prof_note(KID_k_fold_points, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);
+            BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group
+            Gst = dst; Hst = dst + Mr;
+            for (const Scalar &uk : g_us) { Gamma = uk.invert() * Gamma; Eta = uk * Eta; }
+            g_j = 0; g_index++;
+        }
         mcur = h;
         lap(tm ? &tm->ipa_fold : nullptr);
     }

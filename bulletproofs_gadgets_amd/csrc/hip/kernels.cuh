@@ -21,8 +21,13 @@ struct MsmSegs {
     uint32_t len[BPG_MAX_SEGS];
     uint32_t start[BPG_MAX_SEGS + 1];   // prefix of len
     uint32_t msm[BPG_MAX_SEGS];
-    uint32_t nseg;
+    uint32_t lgblk[BPG_MAX_SEGS];       // element e of the segment is point ((e >> lgblk) << (lgblk+1)) | (e & (2^lgblk - 1)): every
+    uint32_t nseg;                      // other block of 2^lgblk points (grouped IPA rounds); 31 = contiguous
 };
+__device__ __forceinline__ uint32_t msm_point_index(const MsmSegs &S, uint32_t seg, uint32_t e) {
+    const uint32_t lg = S.lgblk[seg];
+    return ((e >> lg) << (lg + 1)) | (e & ((1u << lg) - 1u));
+}
 
 // ------------------------------------------------------------------------------------------------ generators
 // one thread per generator: 64 uniform bytes -> Ristretto point (two Elligator maps + add), extended coordinates
@@ -279,33 +284,43 @@ __global__ void __launch_bounds__(256) k_poly_eval(const scm *__restrict__ aL, c
 }
 
 // ------------------------------------------------------------------------------------------------ inner-product rounds
-// Generators are kept UNSCALED: actual G_j = Gamma * gf(j) * Gst[j], actual H_j = Eta * y^-j * gf(j) * Hst[j], where
-// gf(j) = u_ch for j >= n in the first round (G_factors / H_factors of the R1CS padding) and 1 otherwise.
-// MSM scalars for L: a_lo[i]*Gamma*gf(h+i) on Gst[h+i], b_hi[i]*Eta*y^-i on Hst[i];
-//             for R: a_hi[i]*Gamma on Gst[i],           b_lo[i]*Eta*y^-(h+i)*gf(h+i) on Hst[h+i].
-// Also accumulates c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo> per block.
+// Generators are kept UNSCALED: actual G_p = Gamma * gf(p) * Gst[p], actual H_p = Eta * y^-p * gf(p) * Hst[p], where
+// gf(p) = u_ch for p >= n in the first round (G_factors / H_factors of the R1CS padding) and 1 otherwise.
+// Rounds are GROUPED: the stored generators are folded once per group of r rounds (k_fold_points), and sub-round j of a
+// group works on the group-start tables of size M with expanded scalars.  With challenges u_1..u_j since the group start,
+// M_j = M / 2^j, h = M_j / 2, and cG[t] = Gamma * prod_k (bit_k(t) ? u_k : u_k^-1), cH[t] = Eta * prod_k (bit_k(t) ? u_k^-1 : u_k)
+// (bit_k(t) = bit j-k of t; k_tt_advance maintains both tables), the virtual folded generators are
+//     G^(j)[i'] = sum_t cG[t] gf(p) Gst[p],   H^(j)[i'] = sum_t cH[t] y^-p gf(p) Hst[p],   p = i' + t*M_j
+// so that for e = t*h + i (i < h):
+//     L: a_lo[i] cG[t] gf on Gst[t*M_j + h + i],        b_hi[i] cH[t] y^-p gf on Hst[t*M_j + i]
+//     R: a_hi[i] cG[t] gf on Gst[t*M_j + i],            b_lo[i] cH[t] y^-p gf on Hst[t*M_j + h + i]
+// (j = 0 is the plain round).  Also accumulates c_L = <a_lo, b_hi>, c_R = <a_hi, b_lo> per block.
 __global__ void __launch_bounds__(256) k_ipa_prep(const scm *__restrict__ a, const scm *__restrict__ b, const scm *__restrict__ yinvpow,
-                                                  scm Gamma, scm Eta, scm u_ch, uint32_t first_round, uint32_t n, uint32_t h,
+                                                  const scm *__restrict__ cG, const scm *__restrict__ cH, scm u_ch, uint32_t first_group, uint32_t n,
+                                                  uint32_t lgh, uint32_t j,
                                                   scm *__restrict__ sLG, scm *__restrict__ sLH, scm *__restrict__ sRG, scm *__restrict__ sRH,
                                                   scm *__restrict__ partial /* gridDim.x * 2 */) {
     __shared__ scm lds[256];
     scm cL = sc_zero(), cR = sc_zero();
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < h; i += gridDim.x * blockDim.x) {
-        scm alo = a[i], ahi = a[h + i], blo = b[i], bhi = b[h + i];
-        bool pad = first_round && (h + i >= n);
-        scm g = sc_mont_mul(alo, Gamma); if (pad) g = sc_mont_mul(g, u_ch);
-        sLG[i] = g;
-        sLH[i] = sc_mont_mul(sc_mont_mul(bhi, Eta), yinvpow[i]);
-        sRG[i] = sc_mont_mul(ahi, Gamma);
-        scm e = sc_mont_mul(sc_mont_mul(blo, Eta), yinvpow[h + i]); if (pad) e = sc_mont_mul(e, u_ch);
-        sRH[i] = e;
-        cL = sc_add(cL, sc_mont_mul(alo, bhi));
-        cR = sc_add(cR, sc_mont_mul(ahi, blo));
+    const uint32_t h = 1u << lgh, count = h << j;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) {
+        const uint32_t t = e >> lgh, i = e & (h - 1);
+        const uint32_t plo = (t << (lgh + 1)) | i, phi = plo | h;
+        const scm alo = a[i], ahi = a[h + i], blo = b[i], bhi = b[h + i];
+        const scm g = cG[t], eh = cH[t];
+        const bool padlo = first_group && plo >= n, padhi = first_group && phi >= n;
+        scm v;
+        v = sc_mont_mul(alo, g); if (padhi) v = sc_mont_mul(v, u_ch); sLG[e] = v;
+        v = sc_mont_mul(sc_mont_mul(bhi, eh), yinvpow[plo]); if (padlo) v = sc_mont_mul(v, u_ch); sLH[e] = v;
+        v = sc_mont_mul(ahi, g); if (padlo) v = sc_mont_mul(v, u_ch); sRG[e] = v;
+        v = sc_mont_mul(sc_mont_mul(blo, eh), yinvpow[phi]); if (padhi) v = sc_mont_mul(v, u_ch); sRH[e] = v;
+        if (t == 0) { cL = sc_add(cL, sc_mont_mul(alo, bhi)); cR = sc_add(cR, sc_mont_mul(ahi, blo)); }
     }
     scm r;
     r = block_sum_256(cL, lds); if (threadIdx.x == 0) partial[blockIdx.x * 2 + 0] = r;
     r = block_sum_256(cR, lds); if (threadIdx.x == 0) partial[blockIdx.x * 2 + 1] = r;
 }
+__global__ void k_set2(scm *__restrict__ c, uint32_t stride, scm v0, scm v1) { if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = v0; c[stride] = v1; } }
 // c[k] *= w   (k < 2): the Q = w*B term of L and R becomes a scalar on the fixed base B
 __global__ void k_scale2(scm *__restrict__ c, scm w) { if (threadIdx.x < 2 && blockIdx.x == 0) c[threadIdx.x] = sc_mont_mul(c[threadIdx.x], w); }
 
@@ -455,39 +470,44 @@ __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ pa
     if (threadIdx.x == 0) ge_compress(out + 32 * cls, lds[0]);
 }
 
-// Generator fold with a wave-uniform scalar: out[i] = P_i + s * Q_i, P_i = tab[i], Q_i = tab[h + i].
-// naf[k] in {-1,0,1} is the non-adjacent form of s (shared by every lane, so the add/skip branch never diverges).
-// Threads [0,h) fold G with nafG{A,B}, threads [h,2h) fold H with nafH{A,B}; class B applies to i >= split (first round only).
-// The NAF travels in the kernel arguments (SGPRs): nz/neg bit k = digit k non-zero / negative. A wave whose lanes all
-// belong to one class takes the scalar path (s_cbranch on the digit, the addition is skipped, not masked); the at most
-// three waves per launch that straddle a class boundary take the per-lane path.
-struct FoldNaf { uint32_t nz[4][8]; uint32_t neg[4][8]; int32_t top[4]; };
+// Generator fold of one group of r rounds: out[i] = tab[i] + sum_{t=1}^{2^r - 1} s_t * tab[i + t*Mr], i < Mr (Straus: one
+// shared chain of doublings, all scalars wave-uniform, so the add/skip branch never diverges).  Threads [0,Mr) fold G,
+// threads [Mr,2Mr) fold H.  Class B scalars (s_t * u_ch) apply to the padding generators p = i + t*Mr >= n of the first
+// group.  naf holds, per (class, t), the non-adjacent form as two 256-bit masks (nz, neg): [4][nterms][16] words, class =
+// 2*isH + isB.  A wave whose lanes agree on the class of every term takes the scalar path (s_cbranch on the digit: the
+// addition is skipped, not masked); the few waves that straddle a class boundary take the per-lane path.
+struct FoldGroup { uint32_t Mr, nterms, first_group, n; int32_t top; };
 __global__ void __launch_bounds__(256) k_fold_points(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H,
-                                                     ge_ext *__restrict__ out /* 2h */, const FoldNaf naf, uint32_t h, uint32_t split) {
+                                                     ge_ext *__restrict__ out /* 2*Mr */, const uint32_t *__restrict__ naf, const FoldGroup fg) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < 2 * h;
-    if (!live) t = 2 * h - 1;                               // keep whole waves converged; the store is guarded
-    const bool isH = t >= h;
-    const uint32_t i = isH ? t - h : t;
+    const bool live = t < 2 * fg.Mr;
+    if (!live) t = 2 * fg.Mr - 1;                           // keep whole waves converged; the store is guarded
+    const bool isH = t >= fg.Mr;
+    const uint32_t i = isH ? t - fg.Mr : t;
     const ge_niels *tab = isH ? H : G;
-    const int cls = (isH ? 2 : 0) + (i >= split ? 1 : 0);
-    const ge_niels Q = tab[h + i];
+    // bit q of bmask: term q+1 is a padding generator for this lane
+    uint32_t bmask = 0;
+    if (fg.first_group) for (uint32_t q = 0; q < fg.nterms; q++) if (i + (q + 1) * fg.Mr >= fg.n) bmask |= 1u << q;
+    const uint32_t key = (isH ? 0x80000000u : 0u) | bmask;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
     ge_ext acc = ge_identity();
-    const int cls0 = __builtin_amdgcn_readfirstlane(cls);
-    if (__ballot(cls != cls0) == 0ull) {
-        for (int k = naf.top[cls0]; k >= 0; k--) {
-            acc = ge_dbl(acc);
-            const uint32_t nz = (naf.nz[cls0][k >> 5] >> (k & 31)) & 1u;         // scalar
-            if (nz) acc = ge_madd_signed(acc, Q, (naf.neg[cls0][k >> 5] >> (k & 31)) & 1u);
+    if (__ballot(key != key0) == 0ull) {
+        const uint32_t hsel = (key0 >> 31) * 2u;
+        for (int k = fg.top; k >= 0; k--) {
+            acc = ge_dbl(acc);                              // doubling the identity above the top digit is harmless
+            for (uint32_t q = 0; q < fg.nterms; q++) {
+                const uint32_t *d = naf + ((size_t)(hsel + ((key0 >> q) & 1u)) * fg.nterms + q) * 16;     // scalar loads
+                if ((d[k >> 5] >> (k & 31)) & 1u) acc = ge_madd_signed(acc, tab[i + (q + 1) * fg.Mr], (d[8 + (k >> 5)] >> (k & 31)) & 1u);
+            }
         }
     } else {
-        int top = naf.top[0];
-        for (int c = 1; c < 4; c++) top = naf.top[c] > top ? naf.top[c] : top;
-        for (int k = top; k >= 0; k--) {
-            acc = ge_dbl(acc);                              // doubling the identity above a class's top digit is harmless
-            uint32_t nz = 0, ng = 0;
-            for (int c = 0; c < 4; c++) if (c == cls) { nz = (naf.nz[c][k >> 5] >> (k & 31)) & 1u; ng = (naf.neg[c][k >> 5] >> (k & 31)) & 1u; }
-            if (nz) acc = ge_madd_signed(acc, Q, ng);
+        const uint32_t hsel = isH ? 2u : 0u;
+        for (int k = fg.top; k >= 0; k--) {
+            acc = ge_dbl(acc);
+            for (uint32_t q = 0; q < fg.nterms; q++) {
+                const uint32_t *d = naf + ((size_t)(hsel + ((bmask >> q) & 1u)) * fg.nterms + q) * 16;
+                if ((d[k >> 5] >> (k & 31)) & 1u) acc = ge_madd_signed(acc, tab[i + (q + 1) * fg.Mr], (d[8 + (k >> 5)] >> (k & 31)) & 1u);
+            }
         }
     }
     if (live) out[t] = ge_madd(acc, tab[i]);
@@ -608,8 +628,10 @@ __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, uint32_t
     }
 }
 // one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
-__global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys) {
+__global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys,
+                                                         uint32_t *__restrict__ heavy_count) {
     const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key == 0) *heavy_count = 0;                          // list of k_bucket_combine, filled later on this stream
     if (key >= nkeys) return;
     const uint32_t mw = key / P.nb, b = key - mw * P.nb, m = mw / P.W;
     const uint32_t nt = P.tile_start[m + 1] - P.tile_start[m];
@@ -690,26 +712,53 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
             }
         }
         const uint32_t ent = entries[e];
-        const ge_niels q = S.pts[(ent >> 27) & 7u][ent & 0x07ffffffu];
+        const uint32_t sg = (ent >> 27) & 7u;
+        const ge_niels q = S.pts[sg][msm_point_index(S, sg, ent & 0x07ffffffu)];
         acc = ge_madd_signed(acc, q, ent >> 31);
     }
     if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
     else { if (seg_begin == e0) slotA[c] = acc; if (kend >= e1) slotB[c] = acc; }
 }
 
-// one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] otherwise
+// one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] for a
+// bucket spread over a few chunks; a bucket spread over more than HEAVY_CHUNKS chunks (thousands of identical scalars: the
+// -y^h padding terms of the first IPA round, repeated witness values) goes on the heavy list for k_bucket_combine_heavy
+#define HEAVY_CHUNKS 32
 __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                         const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
-                                                        uint32_t nkeys, uint32_t lgCH) {
+                                                        uint32_t nkeys, uint32_t lgCH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
     const uint32_t s0 = starts[k], s1 = starts[k + 1];
     if (s0 == s1) { buckets[k] = ge_identity(); return; }
     const uint32_t c0 = s0 >> lgCH, c1 = (s1 - 1) >> lgCH;
     if (c0 == c1) return;
+    if (c1 - c0 > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
     ge_ext acc = slotB[c0];
     for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
     buckets[k] = acc;
+}
+// one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS
+__global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
+                                                              const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
+                                                              uint32_t lgCH, const uint32_t *__restrict__ heavy) {
+    __shared__ ge_ext lds[256];
+    const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    ge_ext *L = lds + wv * 64;
+    for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {      // wave-uniform trip count; no block barrier inside
+        const uint32_t k = heavy[1 + it];
+        const uint32_t c0 = starts[k] >> lgCH, c1 = (starts[k + 1] - 1) >> lgCH;
+        ge_ext acc = lane == 0 ? slotB[c0] : ge_identity();
+        for (uint32_t c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, slotA[c]);
+        L[lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < d) L[lane] = ge_add(L[lane], L[lane + d]);
+        }
+        if (lane == 0) buckets[k] = L[0];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 // per (msm, window, segment of SEG buckets): sum_b (b+1) * bucket[b] over the segment -> partial
