@@ -440,14 +440,26 @@ bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint
 }
 bpg_status bpg_keccak_selftest(uint64_t seed, uint32_t rounds, int32_t *impl_out, double *ns_out) {
     return guard([&] {
-        uint64_t a[25], b[25];
-        for (int i = 0; i < 25; i++) a[i] = b[i] = seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i * 0xd1342543de82ef95ULL + (seed >> (i & 31));
+        uint64_t a[25], b[25], c[25], d[25];
+        for (int i = 0; i < 25; i++) a[i] = b[i] = c[i] = d[i] = seed * 0x9e3779b97f4a7c15ULL + (uint64_t)i * 0xd1342543de82ef95ULL + (seed >> (i & 31));
+#if defined(__x86_64__)
+        const bool vec = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+#else
+        const bool vec = false;
+#endif
         for (uint32_t r = 0; r < rounds; r++) {
             keccak_f1600_scalar(a); keccak_f1600_host(b);
-            if (std::memcmp(a, b, sizeof a) != 0) throw std::runtime_error("keccak: vector and scalar implementations disagree");
-            a[r % 25] ^= r; b[r % 25] ^= r;
+            if (std::memcmp(a, b, sizeof a) != 0) throw std::runtime_error("keccak: active and scalar implementations disagree");
+#if defined(__x86_64__)
+            if (vec) {
+                keccak_f1600_avx512(c); keccak_f1600_xmm(d);
+                if (std::memcmp(a, c, sizeof a) != 0) throw std::runtime_error("keccak: planes-in-ZMM and scalar implementations disagree");
+                if (std::memcmp(a, d, sizeof a) != 0) throw std::runtime_error("keccak: lanes-in-XMM and scalar implementations disagree");
+            }
+#endif
+            a[r % 25] ^= r; b[r % 25] ^= r; c[r % 25] ^= r; d[r % 25] ^= r;
         }
-        if (impl_out) *impl_out = keccak_have_avx512() ? 1 : 0;
+        if (impl_out) *impl_out = keccak_impl();
         if (ns_out) {
             auto t0 = std::chrono::steady_clock::now();
             for (int r = 0; r < 200000; r++) keccak_f1600_host(b);

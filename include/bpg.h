@@ -186,8 +186,9 @@ bpg_status bpg_range_proof_verify(bpg_verifier *v, const bpg_lc *x, uint32_t n_b
 /* mimc::mimc_hash(preimage) -> Scalar bytes (little-endian); conversions */
 bpg_status bpg_mimc_hash(const uint8_t *preimage, uint64_t len, uint8_t out[32]);
 bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint64_t *n_out);   /* conversions::be_to_scalars */
-/* host Keccak-f[1600] self-check: runs the scalar and (when the CPU has AVX-512F) the vector implementation on `rounds` chained
- * states derived from seed; *impl_out = 1 when the AVX-512 path is the active one. Fails with BPG_ERR_INTERNAL on a mismatch. */
+/* host Keccak-f[1600] self-check: runs the scalar and (when the CPU has AVX-512F+VL) both vector implementations on `rounds` chained
+ * states derived from seed; *impl_out = the active one (0 scalar, 1 planes-in-ZMM, 2 lanes-in-XMM; chosen by a start-up calibration).
+ * Fails with BPG_ERR_INTERNAL on a mismatch. */
 bpg_status bpg_keccak_selftest(uint64_t seed, uint32_t rounds, int32_t *impl_out, double *ns_per_permutation);
 /* host scalar arithmetic (curve25519_dalek::Scalar semantics), exposed for tests: op 0 add, 1 sub, 2 mul, 3 invert, 4 reduce, 5 from_wide(a = 64 B) */
 bpg_status bpg_scalar_op(int32_t op, const uint8_t *a, const uint8_t *b, uint8_t out[32]);

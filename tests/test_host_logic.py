@@ -161,4 +161,4 @@ def test_keccak_vector_and_scalar_implementations_agree():
     for seed in (1, 2, 0xdeadbeef):
         rc = bpg.lib().bpg_keccak_selftest(C.c_uint64(seed), C.c_uint32(3000), C.byref(impl), None)
         assert rc == 0, bpg.lib().bpg_last_error()
-    assert impl.value in (0, 1)
+    assert impl.value in (0, 1, 2)
