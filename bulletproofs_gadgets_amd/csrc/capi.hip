@@ -438,6 +438,20 @@ bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint
         *n_out = s.size();
     });
 }
+bpg_status bpg_rng_draws(const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, const uint8_t rng_seed[32],
+                         uint64_t skip, uint64_t count, int32_t bulk, uint8_t *out) {
+    return guard([&] {
+        REQUIRE(transcript_state && rng_seed && out && (m == 0 || v_blinding));
+        Transcript t = Transcript::from_state(transcript_state);
+        std::vector<Scalar> vb(m);
+        for (uint64_t i = 0; i < m; i++) std::memcpy(vb[i].w, v_blinding + 32 * i, 32);
+        TranscriptRng rng = t.build_rng(vb, rng_seed);
+        uint8_t tmp[64];
+        for (uint64_t i = 0; i < skip; i++) rng.fill_bytes(tmp, 64);
+        if (bulk) rng.fill_draws64(out, count);
+        else for (uint64_t i = 0; i < count; i++) rng.fill_bytes(out + 64 * i, 64);
+    });
+}
 bpg_status bpg_keccak_selftest(uint64_t seed, uint32_t rounds, int32_t *impl_out, double *ns_out) {
     return guard([&] {
         uint64_t a[25], b[25], c[25], d[25];

@@ -519,17 +519,20 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     }
     const double t_rng0 = now_ms();
     I.h_raw.ensure((2 * n ? 2 * n : 1) * 64);
-    {
-        uint8_t *raw = I.h_raw.as<uint8_t>();
-        for (uint64_t i = 0; i < 2 * n; i++) rng.fill_bytes(raw + 64 * i, 64);      // s_L[0..n) then s_R[0..n)
-    }
-    if (tm) tm->rng_host += now_ms() - t_rng0;
     I.raw_rng.ensure((2 * n ? 2 * n : 1) * 64); I.sLR.ensure((2 * n ? 2 * n : 1) * sizeof(scm));
     scm *sL = I.sLR.as<scm>(), *sR = sL + n;
-    if (n) {
-        HIPCHK(hipMemcpyAsync(I.raw_rng.p, I.h_raw.p, 2 * n * 64, hipMemcpyHostToDevice, st));
-        BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), I.raw_rng.as<uint32_t>(), sL, (uint32_t)(2 * n));
+    {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
+        // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
+        uint8_t *raw = I.h_raw.as<uint8_t>();
+        const uint64_t slab = 1u << 16;
+        for (uint64_t i = 0; i < 2 * n; i += slab) {
+            const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
+            rng.fill_draws64(raw + 64 * i, cnt);
+            HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
+            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
+        }
     }
+    if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
     {
         MsmSegs S = seg_new();

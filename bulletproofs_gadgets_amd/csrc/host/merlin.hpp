@@ -114,53 +114,71 @@ __attribute__((target("avx512f"))) static inline void keccak_f1600_avx512(uint64
 // Keccak-f[1600] on 64-bit lanes held one per XMM register (AVX-512VL): 32 vector registers hold the whole state plus the
 // theta vector (no spills, which is what limits the 16-GPR scalar code), and VPTERNLOGQ does chi and the 5-way column
 // parity in one or two instructions each: ~95 operations per round against ~130 (+ spill traffic) for the scalar code.
-__attribute__((target("avx512f,avx512vl"))) static inline void keccak_f1600_xmm(uint64_t s[25]) {
-    static const uint64_t RC[24] = {
-        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-#define KX_LD(i) _mm_loadl_epi64(reinterpret_cast<const __m128i *>(s + (i)))
 #define KX_X3(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0x96)
 #define KX_CHI(a, b, c) _mm_ternarylogic_epi64(a, b, c, 0xD2)
 #define KX_RX(a, d, n) _mm_rol_epi64(_mm_xor_si128(a, d), n)
-    __m128i a00 = KX_LD(0), a01 = KX_LD(1), a02 = KX_LD(2), a03 = KX_LD(3), a04 = KX_LD(4), a05 = KX_LD(5), a06 = KX_LD(6), a07 = KX_LD(7),
-            a08 = KX_LD(8), a09 = KX_LD(9), a10 = KX_LD(10), a11 = KX_LD(11), a12 = KX_LD(12), a13 = KX_LD(13), a14 = KX_LD(14),
-            a15 = KX_LD(15), a16 = KX_LD(16), a17 = KX_LD(17), a18 = KX_LD(18), a19 = KX_LD(19), a20 = KX_LD(20), a21 = KX_LD(21),
-            a22 = KX_LD(22), a23 = KX_LD(23), a24 = KX_LD(24);
-    for (int r = 0; r < 24; r++) {
-        const __m128i c0 = KX_X3(KX_X3(a00, a05, a10), a15, a20), c1 = KX_X3(KX_X3(a01, a06, a11), a16, a21),
-                      c2 = KX_X3(KX_X3(a02, a07, a12), a17, a22), c3 = KX_X3(KX_X3(a03, a08, a13), a18, a23),
-                      c4 = KX_X3(KX_X3(a04, a09, a14), a19, a24);
-        const __m128i d0 = _mm_xor_si128(c4, _mm_rol_epi64(c1, 1)), d1 = _mm_xor_si128(c0, _mm_rol_epi64(c2, 1)),
-                      d2 = _mm_xor_si128(c1, _mm_rol_epi64(c3, 1)), d3 = _mm_xor_si128(c2, _mm_rol_epi64(c4, 1)),
-                      d4 = _mm_xor_si128(c3, _mm_rol_epi64(c0, 1));
-        __m128i b0, b1, b2, b3, b4;
-        b0 = _mm_xor_si128(a00, d0); b1 = KX_RX(a06, d1, 44); b2 = KX_RX(a12, d2, 43); b3 = KX_RX(a18, d3, 21); b4 = KX_RX(a24, d4, 14);
-        const __m128i n00 = _mm_xor_si128(KX_CHI(b0, b1, b2), _mm_loadl_epi64(reinterpret_cast<const __m128i *>(RC + r))),
-                      n01 = KX_CHI(b1, b2, b3), n02 = KX_CHI(b2, b3, b4), n03 = KX_CHI(b3, b4, b0), n04 = KX_CHI(b4, b0, b1);
-        b0 = KX_RX(a03, d3, 28); b1 = KX_RX(a09, d4, 20); b2 = KX_RX(a10, d0, 3); b3 = KX_RX(a16, d1, 45); b4 = KX_RX(a22, d2, 61);
-        const __m128i n05 = KX_CHI(b0, b1, b2), n06 = KX_CHI(b1, b2, b3), n07 = KX_CHI(b2, b3, b4), n08 = KX_CHI(b3, b4, b0), n09 = KX_CHI(b4, b0, b1);
-        b0 = KX_RX(a01, d1, 1); b1 = KX_RX(a07, d2, 6); b2 = KX_RX(a13, d3, 25); b3 = KX_RX(a19, d4, 8); b4 = KX_RX(a20, d0, 18);
-        const __m128i n10 = KX_CHI(b0, b1, b2), n11 = KX_CHI(b1, b2, b3), n12 = KX_CHI(b2, b3, b4), n13 = KX_CHI(b3, b4, b0), n14 = KX_CHI(b4, b0, b1);
-        b0 = KX_RX(a04, d4, 27); b1 = KX_RX(a05, d0, 36); b2 = KX_RX(a11, d1, 10); b3 = KX_RX(a17, d2, 15); b4 = KX_RX(a23, d3, 56);
-        const __m128i n15 = KX_CHI(b0, b1, b2), n16 = KX_CHI(b1, b2, b3), n17 = KX_CHI(b2, b3, b4), n18 = KX_CHI(b3, b4, b0), n19 = KX_CHI(b4, b0, b1);
-        b0 = KX_RX(a02, d2, 62); b1 = KX_RX(a08, d3, 55); b2 = KX_RX(a14, d4, 39); b3 = KX_RX(a15, d0, 41); b4 = KX_RX(a21, d1, 2);
-        const __m128i n20 = KX_CHI(b0, b1, b2), n21 = KX_CHI(b1, b2, b3), n22 = KX_CHI(b2, b3, b4), n23 = KX_CHI(b3, b4, b0), n24 = KX_CHI(b4, b0, b1);
-        a00 = n00; a01 = n01; a02 = n02; a03 = n03; a04 = n04; a05 = n05; a06 = n06; a07 = n07; a08 = n08; a09 = n09;
-        a10 = n10; a11 = n11; a12 = n12; a13 = n13; a14 = n14; a15 = n15; a16 = n16; a17 = n17; a18 = n18; a19 = n19;
-        a20 = n20; a21 = n21; a22 = n22; a23 = n23; a24 = n24;
+#define KX_LD(s, i) _mm_loadl_epi64(reinterpret_cast<const __m128i *>((s) + (i)))
+#define KX_ST(s, i, v) _mm_storel_epi64(reinterpret_cast<__m128i *>((s) + (i)), v)
+#define KX_DECLARE_LOAD(s) \
+    __m128i a00 = KX_LD(s, 0), a01 = KX_LD(s, 1), a02 = KX_LD(s, 2), a03 = KX_LD(s, 3), a04 = KX_LD(s, 4), a05 = KX_LD(s, 5), a06 = KX_LD(s, 6), \
+            a07 = KX_LD(s, 7), a08 = KX_LD(s, 8), a09 = KX_LD(s, 9), a10 = KX_LD(s, 10), a11 = KX_LD(s, 11), a12 = KX_LD(s, 12), a13 = KX_LD(s, 13), \
+            a14 = KX_LD(s, 14), a15 = KX_LD(s, 15), a16 = KX_LD(s, 16), a17 = KX_LD(s, 17), a18 = KX_LD(s, 18), a19 = KX_LD(s, 19), a20 = KX_LD(s, 20), \
+            a21 = KX_LD(s, 21), a22 = KX_LD(s, 22), a23 = KX_LD(s, 23), a24 = KX_LD(s, 24)
+#define KX_STORE(s) \
+    KX_ST(s, 0, a00); KX_ST(s, 1, a01); KX_ST(s, 2, a02); KX_ST(s, 3, a03); KX_ST(s, 4, a04); KX_ST(s, 5, a05); KX_ST(s, 6, a06); KX_ST(s, 7, a07); \
+    KX_ST(s, 8, a08); KX_ST(s, 9, a09); KX_ST(s, 10, a10); KX_ST(s, 11, a11); KX_ST(s, 12, a12); KX_ST(s, 13, a13); KX_ST(s, 14, a14); KX_ST(s, 15, a15); \
+    KX_ST(s, 16, a16); KX_ST(s, 17, a17); KX_ST(s, 18, a18); KX_ST(s, 19, a19); KX_ST(s, 20, a20); KX_ST(s, 21, a21); KX_ST(s, 22, a22); KX_ST(s, 23, a23); \
+    KX_ST(s, 24, a24)
+#define KX_24_ROUNDS(RC) \
+    for (int r_ = 0; r_ < 24; r_++) { \
+        const __m128i c0 = KX_X3(KX_X3(a00, a05, a10), a15, a20), c1 = KX_X3(KX_X3(a01, a06, a11), a16, a21), \
+                      c2 = KX_X3(KX_X3(a02, a07, a12), a17, a22), c3 = KX_X3(KX_X3(a03, a08, a13), a18, a23), \
+                      c4 = KX_X3(KX_X3(a04, a09, a14), a19, a24); \
+        const __m128i d0 = _mm_xor_si128(c4, _mm_rol_epi64(c1, 1)), d1 = _mm_xor_si128(c0, _mm_rol_epi64(c2, 1)), \
+                      d2 = _mm_xor_si128(c1, _mm_rol_epi64(c3, 1)), d3 = _mm_xor_si128(c2, _mm_rol_epi64(c4, 1)), \
+                      d4 = _mm_xor_si128(c3, _mm_rol_epi64(c0, 1)); \
+        __m128i b0, b1, b2, b3, b4; \
+        b0 = _mm_xor_si128(a00, d0); b1 = KX_RX(a06, d1, 44); b2 = KX_RX(a12, d2, 43); b3 = KX_RX(a18, d3, 21); b4 = KX_RX(a24, d4, 14); \
+        const __m128i n00 = _mm_xor_si128(KX_CHI(b0, b1, b2), KX_LD(RC, r_)), \
+                      n01 = KX_CHI(b1, b2, b3), n02 = KX_CHI(b2, b3, b4), n03 = KX_CHI(b3, b4, b0), n04 = KX_CHI(b4, b0, b1); \
+        b0 = KX_RX(a03, d3, 28); b1 = KX_RX(a09, d4, 20); b2 = KX_RX(a10, d0, 3); b3 = KX_RX(a16, d1, 45); b4 = KX_RX(a22, d2, 61); \
+        const __m128i n05 = KX_CHI(b0, b1, b2), n06 = KX_CHI(b1, b2, b3), n07 = KX_CHI(b2, b3, b4), n08 = KX_CHI(b3, b4, b0), n09 = KX_CHI(b4, b0, b1); \
+        b0 = KX_RX(a01, d1, 1); b1 = KX_RX(a07, d2, 6); b2 = KX_RX(a13, d3, 25); b3 = KX_RX(a19, d4, 8); b4 = KX_RX(a20, d0, 18); \
+        const __m128i n10 = KX_CHI(b0, b1, b2), n11 = KX_CHI(b1, b2, b3), n12 = KX_CHI(b2, b3, b4), n13 = KX_CHI(b3, b4, b0), n14 = KX_CHI(b4, b0, b1); \
+        b0 = KX_RX(a04, d4, 27); b1 = KX_RX(a05, d0, 36); b2 = KX_RX(a11, d1, 10); b3 = KX_RX(a17, d2, 15); b4 = KX_RX(a23, d3, 56); \
+        const __m128i n15 = KX_CHI(b0, b1, b2), n16 = KX_CHI(b1, b2, b3), n17 = KX_CHI(b2, b3, b4), n18 = KX_CHI(b3, b4, b0), n19 = KX_CHI(b4, b0, b1); \
+        b0 = KX_RX(a02, d2, 62); b1 = KX_RX(a08, d3, 55); b2 = KX_RX(a14, d4, 39); b3 = KX_RX(a15, d0, 41); b4 = KX_RX(a21, d1, 2); \
+        const __m128i n20 = KX_CHI(b0, b1, b2), n21 = KX_CHI(b1, b2, b3), n22 = KX_CHI(b2, b3, b4), n23 = KX_CHI(b3, b4, b0), n24 = KX_CHI(b4, b0, b1); \
+        a00 = n00; a01 = n01; a02 = n02; a03 = n03; a04 = n04; a05 = n05; a06 = n06; a07 = n07; a08 = n08; a09 = n09; \
+        a10 = n10; a11 = n11; a12 = n12; a13 = n13; a14 = n14; a15 = n15; a16 = n16; a17 = n17; a18 = n18; a19 = n19; \
+        a20 = n20; a21 = n21; a22 = n22; a23 = n23; a24 = n24; \
     }
-#define KX_ST(i, v) _mm_storel_epi64(reinterpret_cast<__m128i *>(s + (i)), v)
-    KX_ST(0, a00); KX_ST(1, a01); KX_ST(2, a02); KX_ST(3, a03); KX_ST(4, a04); KX_ST(5, a05); KX_ST(6, a06); KX_ST(7, a07); KX_ST(8, a08);
-    KX_ST(9, a09); KX_ST(10, a10); KX_ST(11, a11); KX_ST(12, a12); KX_ST(13, a13); KX_ST(14, a14); KX_ST(15, a15); KX_ST(16, a16);
-    KX_ST(17, a17); KX_ST(18, a18); KX_ST(19, a19); KX_ST(20, a20); KX_ST(21, a21); KX_ST(22, a22); KX_ST(23, a23); KX_ST(24, a24);
-#undef KX_LD
-#undef KX_X3
-#undef KX_CHI
-#undef KX_RX
-#undef KX_ST
+static const uint64_t KECCAK_RC_XMM[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+__attribute__((target("avx512f,avx512vl"))) static inline void keccak_f1600_xmm(uint64_t s[25]) {
+    KX_DECLARE_LOAD(s);
+    KX_24_ROUNDS(KECCAK_RC_XMM)
+    KX_STORE(s);
+}
+// TranscriptRng steady state, `count` draws of 64 bytes with the sponge kept in registers between draws.  Per draw
+// (STROBE meta_ad(le32(64)) + prf(64) with the position at 64): bytes 64..73 and 167 take fixed XOR constants, one
+// permutation, then the first 64 bytes are the output and are zeroed (PRF).  Caller has folded the old pos_begin into byte 64.
+__attribute__((target("avx512f,avx512vl"))) static inline void strobe_rng_bulk64_xmm(uint64_t s[25], uint8_t *dest, size_t count,
+                                                                                     uint64_t k8, uint64_t k9, uint64_t k20) {
+    KX_DECLARE_LOAD(s);
+    const __m128i x8 = _mm_cvtsi64_si128((long long)k8), x9 = _mm_cvtsi64_si128((long long)k9), x20 = _mm_cvtsi64_si128((long long)k20);
+    for (size_t i = 0; i < count; i++) {
+        a08 = _mm_xor_si128(a08, x8); a09 = _mm_xor_si128(a09, x9); a20 = _mm_xor_si128(a20, x20);
+        KX_24_ROUNDS(KECCAK_RC_XMM)
+        uint64_t *o = reinterpret_cast<uint64_t *>(dest + 64 * i);
+        KX_ST(o, 0, a00); KX_ST(o, 1, a01); KX_ST(o, 2, a02); KX_ST(o, 3, a03); KX_ST(o, 4, a04); KX_ST(o, 5, a05); KX_ST(o, 6, a06); KX_ST(o, 7, a07);
+        a00 = a01 = a02 = a03 = a04 = a05 = a06 = a07 = _mm_setzero_si128();
+    }
+    KX_STORE(s);
 }
 
 // Which one is fastest depends on the core (EPYC 9575F / Zen 5: lanes-in-XMM 154 ns, scalar 177 ns, planes-in-ZMM 228 ns, the
@@ -239,6 +257,26 @@ public:
     void ad(const uint8_t *d, size_t n, bool more) { begin_op(FLAG_A, more); absorb(d, n); }
     void prf(uint8_t *d, size_t n, bool more) { begin_op(FLAG_I | FLAG_A | FLAG_C, more); squeeze(d, n); }
     void key(const uint8_t *d, size_t n, bool more) { begin_op(FLAG_A | FLAG_C, more); overwrite(d, n); }
+    // `count` TranscriptRng draws of 64 bytes each (meta_ad(le32(64)) + prf(64)); same bytes as the generic path
+    void rng_draws64(uint8_t *dest, size_t count) {
+        while (count && pos_ != 64) {                        // reach the steady state through the generic operations
+            const uint8_t l4[4] = {64, 0, 0, 0}; meta_ad(l4, 4, false); prf(dest, 64, false); dest += 64; count--;
+        }
+        if (!count) return;
+        // at pos 64: header {old pos_begin, M|A} + 64,0,0,0 + header {65, I|A|C} fill bytes 64..71; run_f pads at 72, 73 and R+1
+        const uint64_t k8 = (0x12ULL << 8) | (64ULL << 16) | (65ULL << 48) | (0x07ULL << 56), k9 = 71ULL | (0x04ULL << 8), k20 = 0x80ULL << 56;
+        st_[8] ^= pos_begin_;
+#if defined(__x86_64__)
+        if (keccak_impl() == 2) strobe_rng_bulk64_xmm(st_, dest, count, k8, k9, k20);
+        else
+#endif
+        for (size_t i = 0; i < count; i++) {
+            st_[8] ^= k8; st_[9] ^= k9; st_[20] ^= k20;
+            keccak_f1600_host(st_);
+            std::memcpy(dest + 64 * i, st_, 64); std::memset(st_, 0, 64);
+        }
+        pos_ = 64; pos_begin_ = 0; cur_flags_ = FLAG_I | FLAG_A | FLAG_C;
+    }
     void export_state(uint8_t out[203]) const { std::memcpy(out, st_, 200); out[200] = pos_; out[201] = pos_begin_; out[202] = cur_flags_; }
     void import_state(const uint8_t in[203]) { std::memcpy(st_, in, 200); pos_ = in[200]; pos_begin_ = in[201]; cur_flags_ = in[202]; }
 private:
@@ -275,6 +313,7 @@ class TranscriptRng {
 public:
     explicit TranscriptRng(const Strobe128 &s) : s_(s) {}
     void fill_bytes(uint8_t *dest, size_t n) { uint8_t l4[4]; le32(l4, n); s_.meta_ad(l4, 4, false); s_.prf(dest, n, false); }
+    void fill_draws64(uint8_t *dest, size_t count) { s_.rng_draws64(dest, count); }      // count x fill_bytes(.., 64), bulk
     Scalar random_scalar() { uint8_t b[64]; fill_bytes(b, 64); return Scalar::from_wide(b); }
     static void le32(uint8_t b[4], size_t n) { b[0] = (uint8_t)n; b[1] = (uint8_t)(n >> 8); b[2] = (uint8_t)(n >> 16); b[3] = (uint8_t)(n >> 24); }
 private:

@@ -186,6 +186,10 @@ bpg_status bpg_range_proof_verify(bpg_verifier *v, const bpg_lc *x, uint32_t n_b
 /* mimc::mimc_hash(preimage) -> Scalar bytes (little-endian); conversions */
 bpg_status bpg_mimc_hash(const uint8_t *preimage, uint64_t len, uint8_t out[32]);
 bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint64_t *n_out);   /* conversions::be_to_scalars */
+/* test hook: `count` 64-byte TranscriptRng draws (merlin build_rng().rekey_with_witness_bytes("v_blinding")*.finalize(seed)), after
+ * `skip` draws through the generic STROBE operations; bulk != 0 uses the prover's in-register bulk path. Same bytes either way. */
+bpg_status bpg_rng_draws(const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, const uint8_t rng_seed[32],
+                         uint64_t skip, uint64_t count, int32_t bulk, uint8_t *out);
 /* host Keccak-f[1600] self-check: runs the scalar and (when the CPU has AVX-512F+VL) both vector implementations on `rounds` chained
  * states derived from seed; *impl_out = the active one (0 scalar, 1 planes-in-ZMM, 2 lanes-in-XMM; chosen by a start-up calibration).
  * Fails with BPG_ERR_INTERNAL on a mismatch. */

@@ -162,3 +162,25 @@ def test_keccak_vector_and_scalar_implementations_agree():
         rc = bpg.lib().bpg_keccak_selftest(C.c_uint64(seed), C.c_uint32(3000), C.byref(impl), None)
         assert rc == 0, bpg.lib().bpg_last_error()
     assert impl.value in (0, 1, 2)
+
+
+def test_bulk_rng_draws_match_generic_strobe_path_and_oracle():
+    """The prover draws s_L, s_R through an in-register bulk path (merlin.hpp rng_draws64); it must give the bytes of
+    meta_ad(le32(64)) + prf(64) per draw, from any starting position, and reduce to the oracle's Scalar::random values."""
+    import ctypes as C
+    import oracle_lib as O
+    t = bpg.Transcript(b"rng-bulk")
+    t.append_message(b"x", b"y" * 37)
+    vb = b"".join(bytes([i + 1]) + bytes(31) for i in range(3))
+    seed = bytes(range(32))
+    count = 300
+    outs = []
+    for skip, bulk in ((0, 0), (0, 1), (5, 1), (5, 0)):
+        out = C.create_string_buffer(64 * count)
+        rc = bpg.lib().bpg_rng_draws(t.state, C.c_uint64(3), vb, seed, C.c_uint64(skip), C.c_uint64(count), C.c_int32(bulk), out)
+        assert rc == 0, bpg.lib().bpg_last_error()
+        outs.append(out.raw)
+    assert outs[0] == outs[1] and outs[2] == outs[3] and outs[0][64 * 5:] == outs[2][:64 * (count - 5)]
+    want = O.rng_scalars(t.state, vb, seed, 8)
+    got = b"".join(bpg.scalar_op("from_wide", outs[1][64 * i:64 * i + 64]) for i in range(8))
+    assert got == b"".join(want)
