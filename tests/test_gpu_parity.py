@@ -384,3 +384,44 @@ def test_skewed_witness_distributions(ctx):
         l, r, o = p.allocate_multiplier((sc(7), sc(9)))
         p.constrain(bpg.LinearCombination.of(o) - sc(63))
     check_against_oracle(ctx, p, t, cs, 512)
+
+
+@pytest.mark.parametrize("tt_lg,group", [(0, 1), (0, 2), (0, 3), (0, 5), (3, 1), (3, 2), (3, 3), (5, 4), (8, 2), (9, 5), (11, 3)])
+def test_ipa_schedules_give_identical_proofs(tt_lg, group, monkeypatch):
+    """The inner-product argument can be scheduled in many ways - generator folds grouped over `group` rounds, generators frozen
+    below 2^tt_lg with window tables, or plain round-by-round folding (tt_lg = 0, group = 1).  Every schedule must give the
+    oracle's bytes, including the first-round padding classes (n < N) falling on any term of a grouped fold."""
+    monkeypatch.setenv("BPG_TT_LG", str(tt_lg))
+    monkeypatch.setenv("BPG_FOLD_GROUP", str(group))
+    c = bpg.Context(0)                       # the schedule is read when the context is created
+    try:
+        # 1-block MiMC preimage: n = 972, N = 1024 (52 padding generators)
+        a = workloads.mimc_preimage(c, nbytes=20, seed=3, label=b"MiMCHash")
+        inst = a.prover.instance()
+        assert (inst.n, a.gens_capacity) == (972, 1024)
+        og = O.Gens(1024)
+        c.gens_ensure(1024)
+        res = c.upload(inst)
+        proof, st_after = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)
+        rc, want, st_want = O.prove(og, a.transcript.state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
+        assert rc == 0 and proof == want and st_after == st_want
+        res.free()
+        # n just above N/2 (worst padding: almost half of the generators are padding) and n = N
+        for nbits in (33, 64):
+            b = workloads.bounds_check_64(c, seed=nbits) if nbits == 64 else None
+            if b is None:
+                t = bpg.Transcript(b"RangeProof")
+                p = bpg.Prover(c, t)
+                x = bpg.be_to_scalar(bytes([1, 2, 3, 4, 1]))
+                bpg.range_proof(p, x, 40, x)                               # 40 multipliers, N = 64: 24 padding generators
+                inst2, state2, cap = p.instance(), t.state, 64
+            else:
+                inst2, state2, cap = b.prover.instance(), b.transcript.state, b.gens_capacity
+            c.gens_ensure(cap)
+            res = c.upload(inst2)
+            proof, _ = res.prove(state2, inst2.v_blinding, bytes(32), 0)
+            rc, want, _ = O.prove(O.Gens(cap), state2, to_oracle(inst2), inst2.v_blinding, bytes(32), O.FLAG_FAST_MSM)
+            assert rc == 0 and proof == want, (tt_lg, group, nbits)
+            res.free()
+    finally:
+        c.close()
