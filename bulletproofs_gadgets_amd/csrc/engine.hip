@@ -317,7 +317,7 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
     const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
     const uint32_t nkeys = nmsm * W * nb;
-    const uint32_t seg = nb < 32 ? nb : 32, nsegpw = nb / seg;
+    uint32_t seg = 8; if (const char *e = std::getenv("BPG_RSEG")) seg = (uint32_t)std::atoi(e); if (seg > nb) seg = nb; const uint32_t nsegpw = nb / seg;
     const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
     // tiling plan: the segments of one MSM are contiguous; tiles never span two MSMs
     MsmPlan P; std::memset(&P, 0, sizeof P);
