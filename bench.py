@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--baseline-leaves", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-profile", action="store_true", help="one extra, untimed step with HIP events around every kernel")
-    ap.add_argument("--in-flight", type=int, default=4, help="secondary measurement: independent proofs in flight on ONE GPU (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=6, help="secondary measurement: independent proofs in flight on ONE GPU (0 = skip)")
     args = ap.parse_args()
 
     import torch

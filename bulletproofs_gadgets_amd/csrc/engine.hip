@@ -134,6 +134,7 @@ struct Engine::Impl {
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c;
     PinBuf h_naf;
+    bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
     PinBuf h_raw, h_small;
@@ -152,6 +153,7 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
@@ -759,7 +761,15 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
             FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
             ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            BPG_LAUNCH(I, k_fold_points, dim3(cdiv(2 * Mr, 256)), dim3(256), Gst, Hst, I.scratch_ext.as<ge_ext>(), I.naf.as<uint32_t>(), fg);
+            {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
+                const dim3 grid(cdiv(2 * Mr, 256)), block(256);
+                ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
+                if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 3 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 7 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 15 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);
+                else BPG_LAUNCH(I, k_fold_points, grid, block, Gst, Hst, fo, nf, fg);
+            }
             // bookkeeping for the roofline: 2*g_M points read + 2*Mr written at 32 B (information content) resp. 96/128 B (device formats);
             // field multiplications: 8 per doubling, 7 per mixed addition
             I.prof_note(KID_k_fold_points, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);

@@ -513,6 +513,53 @@ __global__ void __launch_bounds__(256) k_fold_points(const ge_niels *__restrict_
     if (live) out[t] = ge_madd(acc, tab[i]);
 }
 
+// Same fold with the 2^r - 1 addends of every lane held in registers (NT * 24 VGPRs: 168 for r = 3, which leaves one wave per
+// SIMD; the kernel is a single dependent chain per lane anyway): each table point is read from memory exactly once instead
+// of once per non-zero NAF digit (~84 times), which was 165x the algorithmic traffic out of the Infinity Cache.
+// (addends are 15 named variables, not an array: the compiler keeps an indexed local array in scratch memory)
+#define BPG_FOLD_VARS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+template <int NT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) k_fold_points_reg(
+        const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, ge_ext *__restrict__ out /* 2*Mr */, const uint32_t *__restrict__ naf, const FoldGroup fg) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < 2 * fg.Mr;
+    if (!live) t = 2 * fg.Mr - 1;
+    const bool isH = t >= fg.Mr;
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const ge_niels *tab = isH ? H : G;
+#define BPG_FOLD_LOAD(j) ge_niels p##j; if (j <= NT) p##j = tab[i + (size_t)j * fg.Mr];
+    BPG_FOLD_VARS(BPG_FOLD_LOAD)
+#undef BPG_FOLD_LOAD
+    uint32_t bmask = 0;
+    if (fg.first_group) for (uint32_t q = 0; q < (uint32_t)NT; q++) if (i + (q + 1) * fg.Mr >= fg.n) bmask |= 1u << q;
+    const uint32_t key = (isH ? 0x80000000u : 0u) | bmask;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    const bool uniform = __ballot(key != key0) == 0ull;
+    const uint32_t hsel = isH ? 2u : 0u;
+    ge_ext acc = ge_identity();
+    for (int k = fg.top; k >= 0; k--) {
+        acc = ge_dbl(acc);
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)NT; q++) {
+            // wave-uniform digit (scalar loads, s_cbranch) when every lane agrees on the class of every term
+            const uint32_t cls = uniform ? (uint32_t)__builtin_amdgcn_readfirstlane(hsel + ((bmask >> q) & 1u)) : hsel + ((bmask >> q) & 1u);
+            const uint32_t *d = naf + ((size_t)cls * NT + q) * 16;
+            const uint32_t nz = (d[k >> 5] >> (k & 31)) & 1u, ng = (d[8 + (k >> 5)] >> (k & 31)) & 1u;
+            if (uniform ? (__builtin_amdgcn_readfirstlane(nz) != 0) : (nz != 0)) {
+                ge_niels Q = p1;
+                switch (q) {                                   // q is wave-uniform: scalar branches, 24 moves
+#define BPG_FOLD_PICK(j) case j - 1: if (j <= NT) Q = p##j; break;
+                    BPG_FOLD_VARS(BPG_FOLD_PICK)
+#undef BPG_FOLD_PICK
+                    default: break;
+                }
+                acc = ge_madd_signed(acc, Q, ng);
+            }
+        }
+    }
+    if (live) out[t] = ge_madd(acc, tab[i]);
+}
+
 // ------------------------------------------------------------------------------------------------ verifier
 // compressed points -> affine Niels (Z = 1 after decoding, so no inversion); ok[i] = 0 for invalid encodings
 __global__ void __launch_bounds__(64) k_decompress(const uint8_t *__restrict__ in, ge_niels *__restrict__ out, uint32_t *__restrict__ ok, uint32_t count) {
