@@ -132,7 +132,7 @@ struct Engine::Impl {
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
-    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c;
+    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table;
     PinBuf h_naf;
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -164,6 +164,14 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipMemcpyAsync(impl_->small_in.p, h, 64, hipMemcpyHostToDevice, impl_->st));
     hipLaunchKernelGGL(k_init_bases, dim3(1), dim3(64), 0, impl_->st, impl_->small_in.as<uint32_t>(), impl_->bases.as<ge_niels>());
     HIPCHK(hipGetLastError());
+    // window tables of B and B_blinding for k_pedersen (64 windows x 8 multiples each, 128 KB)
+    impl_->tt_bases.ensure((size_t)3 * TT_WINDOWS * sizeof(ge_ext));
+    impl_->ped_table.ensure((size_t)3 * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
+    hipLaunchKernelGGL(k_tt_bases, dim3(1), dim3(256), 0, impl_->st, impl_->bases.as<ge_niels>(), impl_->bases.as<ge_niels>() + 1, impl_->bases.as<ge_niels>(),
+                       impl_->tt_bases.as<ge_ext>(), 1u);
+    hipLaunchKernelGGL(k_tt_multiples, dim3(cdiv(3 * TT_WINDOWS, 256)), dim3(256), 0, impl_->st, impl_->tt_bases.as<ge_ext>(), impl_->ped_table.as<ge_pniels>(),
+                       (uint32_t)(3 * TT_WINDOWS));
+    HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(impl_->st));
 }
 
@@ -175,7 +183,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release();
     (void)hipStreamDestroy(impl_->st);
@@ -303,8 +311,8 @@ void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, u
     I.small_sc.ensure(2 * k * 32); I.comp.ensure(k * 32);
     HIPCHK(hipMemcpyAsync(I.small_sc.p, hv.data(), k * 32, hipMemcpyHostToDevice, I.st));
     HIPCHK(hipMemcpyAsync(I.small_sc.as<uint8_t>() + k * 32, hr.data(), k * 32, hipMemcpyHostToDevice, I.st));
-    BPG_LAUNCH(I, k_pedersen, dim3(cdiv(k, 64)), dim3(64), I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + k * 8,
-                       I.bases.as<ge_niels>(), I.comp.as<uint8_t>(), (uint32_t)k);
+    BPG_LAUNCH(I, k_pedersen, dim3((uint32_t)k), dim3(64), I.small_sc.as<uint32_t>(), I.small_sc.as<uint32_t>() + k * 8,
+                       I.ped_table.as<ge_pniels>(), I.comp.as<uint8_t>(), (uint32_t)k);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(out, I.comp.p, k * 32, hipMemcpyDeviceToHost, I.st));
     HIPCHK(hipStreamSynchronize(I.st));

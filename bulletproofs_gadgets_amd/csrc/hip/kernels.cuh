@@ -95,24 +95,6 @@ __global__ void k_init_bases(const uint32_t *__restrict__ hash64, ge_niels *__re
     bases[2] = ge_to_niels(S, fe_invert(S.Z));
 }
 
-// Pedersen commitments v*B + r*B_blinding, one per thread (Shamir's trick over the 3-entry base table), compressed.
-// v, r are plain 256-bit little-endian integers below 2^255 (v may be an unreduced Scalar::from_bits value).
-__global__ void __launch_bounds__(64) k_pedersen(const uint32_t *__restrict__ v, const uint32_t *__restrict__ r,
-                                                 const ge_niels *__restrict__ bases, uint8_t *__restrict__ out, uint32_t count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    uint32_t vw[8], rw[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { vw[k] = v[8 * (size_t)i + k]; rw[k] = r[8 * (size_t)i + k]; }
-    ge_ext acc = ge_identity();
-    for (int b = 254; b >= 0; b--) {
-        acc = ge_dbl(acc);
-        uint32_t sel = ((vw[b >> 5] >> (b & 31)) & 1u) | (((rw[b >> 5] >> (b & 31)) & 1u) << 1);
-        if (sel) acc = ge_madd(acc, bases[sel - 1]);
-    }
-    ge_compress(out + 32 * (size_t)i, acc);
-}
-
 // unit-test hook for the device field arithmetic (the inline-asm paths cannot be compiled for the host):
 // op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 chain (mixed ops on weakly reduced intermediates); inputs are raw 256-bit values
 __global__ void __launch_bounds__(64) k_test_fe(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint8_t *__restrict__ out, uint32_t n, uint32_t op) {
@@ -468,6 +450,39 @@ __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ pa
         __syncthreads();
     }
     if (threadIdx.x == 0) ge_compress(out + 32 * cls, lds[0]);
+}
+
+// Pedersen commitments v*B + r*B_blinding from the window tables of the two fixed bases (k_tt_bases / k_tt_multiples on
+// {B, B_blinding} at context creation): one wave per commitment, lane w adds the two table entries of 4-bit window w, the
+// 64 partial sums meet in an LDS tree and lane 0 compresses - 8 dependent point additions instead of 255 doublings.
+// v, r are plain 256-bit little-endian integers below 2^255 (v may be an unreduced Scalar::from_bits value), so the signed
+// recoding (digit in [-8, 8], carry into the next window) never carries out of window 63.
+__device__ __forceinline__ int32_t ped_digit(const uint32_t w[8], uint32_t win) {
+    uint32_t carry = 0; int32_t d = 0;
+    for (uint32_t j = 0; j <= win; j++) {
+        const uint32_t nib = ((w[j >> 3] >> (4 * (j & 7u))) & 15u) + carry;
+        carry = nib > 8u; d = (int32_t)nib - (carry ? 16 : 0);
+    }
+    return d;
+}
+__global__ void __launch_bounds__(64) k_pedersen(const uint32_t *__restrict__ v, const uint32_t *__restrict__ r,
+                                                 const ge_pniels *__restrict__ table /* [2][64][8] */, uint8_t *__restrict__ out, uint32_t count) {
+    __shared__ ge_ext lds[64];
+    const uint32_t i = blockIdx.x, win = threadIdx.x;
+    if (i >= count) return;
+    uint32_t vw[8], rw[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { vw[k] = v[8 * (size_t)i + k]; rw[k] = r[8 * (size_t)i + k]; }
+    ge_ext acc = ge_identity();
+    const int32_t dv = ped_digit(vw, win), dr = ped_digit(rw, win);
+    if (dv != 0) acc = ge_add_pniels_signed(acc, table[(size_t)win * TT_MULTS + (dv < 0 ? -dv : dv) - 1], dv < 0);
+    if (dr != 0) acc = ge_add_pniels_signed(acc, table[(size_t)(TT_WINDOWS + win) * TT_MULTS + (dr < 0 ? -dr : dr) - 1], dr < 0);
+    lds[win] = acc; __syncthreads();
+    for (uint32_t d = 32; d > 0; d >>= 1) {
+        if (win < d) lds[win] = ge_add(lds[win], lds[win + d]);
+        __syncthreads();
+    }
+    if (win == 0) ge_compress(out + 32 * (size_t)i, lds[0]);
 }
 
 // Generator fold of one group of r rounds: out[i] = tab[i] + sum_{t=1}^{2^r - 1} s_t * tab[i + t*Mr], i < Mr (Straus: one
