@@ -184,3 +184,48 @@ def test_bulk_rng_draws_match_generic_strobe_path_and_oracle():
     want = O.rng_scalars(t.state, vb, seed, 8)
     got = b"".join(bpg.scalar_op("from_wide", outs[1][64 * i:64 * i + 64]) for i in range(8))
     assert got == b"".join(want)
+
+
+def test_or_conjunction_assembly_counts_on_the_verifier_side():
+    """src/or/or_conjunction.rs:4-38 with the recording buffer of src/cs_buffer.rs: the clauses' multipliers are replayed into the
+    parent, then one product chain per element of the Cartesian product of the clauses' explicit constraints.
+    BOUND with 1-byte bounds = 2 x 8-bit range proofs: 16 allocate_multiplier calls, 35 explicit constraints."""
+    def bound_clause(cs, coms):
+        bpg.BoundsCheck(bytes([10]), bytes([100])).verify(cs, [coms[0]], coms[1:3])
+
+    v0 = bpg.Verifier(bpg.Transcript(b"or"))
+    c0 = [v0.commit(bytes(32)) for _ in range(3)]
+    bound_clause(v0, c0)
+    i0 = v0.instance()
+    assert (i0.n, i0.q) == (16, 35)
+
+    for k in (2, 3):
+        v = bpg.Verifier(bpg.Transcript(b"or"))
+        coms = [v.commit(bytes(32)) for _ in range(3 * k)]
+        buf = bpg.ConstraintBuffer(v, False)
+        for j in range(k):
+            bound_clause(buf, coms[3 * j:3 * j + 3])
+            buf.rewind()
+        assert buf.next_multiplier() == 16 * k
+        bpg.or_conjunction(v, buf)
+        i = v.instance()
+        products = 35 ** k
+        assert i.n == 16 * k + products * (k - 1)
+        assert i.q == products + 2 * products * (k - 1)          # one constraint per product + 2 per multiply()
+    # nested: OR( A, OR(B, C) ) - the inner OR replays into the outer clause's buffer
+    v = bpg.Verifier(bpg.Transcript(b"or"))
+    coms = [v.commit(bytes(32)) for _ in range(9)]
+    outer = bpg.ConstraintBuffer(v, False)
+    bound_clause(outer, coms[0:3]); outer.rewind()
+    inner = bpg.ConstraintBuffer(outer, False)
+    bound_clause(inner, coms[3:6]); inner.rewind()
+    bound_clause(inner, coms[6:9]); inner.rewind()
+    bpg.or_conjunction(outer, inner); outer.rewind()
+    bpg.or_conjunction(v, outer)
+    i = v.instance()
+    inner_n, inner_c = 32 + 35 * 35, 35 * 35                     # the inner OR as a clause: multipliers, explicit constraints
+    assert i.n == 16 + inner_n + 35 * inner_c
+    # an OR over no clauses adds nothing
+    v = bpg.Verifier(bpg.Transcript(b"or"))
+    bpg.or_conjunction(v, bpg.ConstraintBuffer(v, False))
+    assert (v.instance().n, v.instance().q) == (0, 0)
