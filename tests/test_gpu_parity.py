@@ -425,3 +425,21 @@ def test_ipa_schedules_give_identical_proofs(tt_lg, group, monkeypatch):
             res.free()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("blocks,N", [(33, 1 << 15), (134, 1 << 17)])
+def test_fold_group_sizes_above_the_tail(ctx, blocks, N):
+    """Byte parity where the generator folds are live with the default schedule: N = 2^15 (one fold of a single round, then the
+    table-driven tail) and N = 2^17 (one fold of three rounds with all seven addends in registers, padding generators on the
+    last term)."""
+    a = workloads.mimc_preimage(ctx, nbytes=32 * (blocks - 1) + 5, seed=blocks, label=b"MiMCHash")
+    inst = a.prover.instance()
+    assert inst.n == 972 * blocks and a.gens_capacity == N
+    ctx.gens_ensure(N)
+    G, Hh = ctx.gens_export(0, N)
+    og = O.Gens(compressed=(G, Hh))
+    res = ctx.upload(inst)
+    proof, st_after = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)
+    rc, want, st_want = O.prove(og, a.transcript.state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
+    assert rc == 0 and proof == want and st_after == st_want
+    res.free()
