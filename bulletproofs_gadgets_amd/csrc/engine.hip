@@ -89,7 +89,7 @@ struct DeviceCircuit {
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -132,7 +132,7 @@ struct Engine::Impl {
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
-    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table;
+    DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
     PinBuf h_naf;
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -183,7 +183,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release();
     (void)hipStreamDestroy(impl_->st);
@@ -531,6 +531,25 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.h_raw.ensure((2 * n ? 2 * n : 1) * 64);
     I.raw_rng.ensure((2 * n ? 2 * n : 1) * 64); I.sLR.ensure((2 * n ? 2 * n : 1) * sizeof(scm));
     scm *sL = I.sLR.as<scm>(), *sR = sL + n;
+    // S = <s_L, G> + <s_R, H> + sb * B_blinding is accumulated in pieces as the draws arrive: <s_L, G> once s_L is complete,
+    // the first 7/8 of <s_R, H> next, and only the last eighth (+ the blinding term) after the chain has ended.
+    I.s_parts.ensure(4 * sizeof(ge_ext));
+    struct Piece { uint64_t a, b; } pieces[3] = {{0, n}, {n, n + (n - n / 8)}, {n + (n - n / 8), 2 * n}};
+    uint32_t next_piece = 0, nparts = 0;
+    auto launch_pieces = [&](uint64_t drawn) {
+        while (next_piece < 3 && pieces[next_piece].b <= drawn) {
+            const Piece pc = pieces[next_piece];
+            const bool last = next_piece == 2;
+            next_piece++;
+            if (pc.b == pc.a && !last) continue;
+            MsmSegs S = seg_new();
+            if (pc.a < n) seg_push(S, sL + pc.a, Gtab + pc.a, (uint32_t)(std::min<uint64_t>(pc.b, n) - pc.a), 0);
+            if (pc.b > n) { const uint64_t a2 = std::max<uint64_t>(pc.a, n) - n; seg_push(S, sR + a2, Htab + a2, (uint32_t)(pc.b - n - a2), 0); }
+            if (last) seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 0);
+            I.msm(S, 1, I.s_parts.as<ge_ext>() + nparts);
+            nparts++;
+        }
+    };
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
         uint8_t *raw = I.h_raw.as<uint8_t>();
@@ -540,17 +559,13 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             rng.fill_draws64(raw + 64 * i, cnt);
             HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
             BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
+            if (i + cnt < 2 * n) launch_pieces(i + cnt);
         }
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
-    {
-        MsmSegs S = seg_new();
-        seg_push(S, sL, Gtab, (uint32_t)n, 0);
-        seg_push(S, sR, Htab, (uint32_t)n, 0);
-        seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 0);
-        I.msm(S, 1, I.msm_result.as<ge_ext>() + 2);
-    }
+    launch_pieces(2 * n);
+    BPG_LAUNCH(I, k_sum_points, dim3(1), dim3(64), I.s_parts.as<ge_ext>(), nparts, I.msm_result.as<ge_ext>() + 2);
     BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
     HIPCHK(hipGetLastError());
     uint8_t pts[96];
