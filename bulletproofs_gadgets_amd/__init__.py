@@ -279,6 +279,11 @@ class ResidentCircuit:
                                            out, C.byref(ln), C.byref(tm) if timings else None))
         return (out.raw[:ln.value], ts.raw[:203], tm.as_dict()) if timings else (out.raw[:ln.value], ts.raw[:203])
 
+    def verify(self, transcript_state, commitments, proof, seed=bytes(32), flags=0):
+        """bpg_r1cs_verify_resident: 0 = accepted, 3 = VERIFICATION_ERROR, 2 = FORMAT_ERROR, 1 = INVALID_GENERATORS_LENGTH."""
+        ts = _buf(203); ts.raw = bytes(transcript_state)
+        return lib().bpg_r1cs_verify_resident(self.ctx._h, self._h, ts, C.c_uint64(self.m), commitments, proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags))
+
     def free(self):
         if self._h:
             lib().bpg_r1cs_free(self.ctx._h, self._h)

@@ -225,6 +225,18 @@ bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t 
     });
 }
 
+bpg_status bpg_r1cs_verify_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t ts[BPG_TRANSCRIPT_STATE_BYTES], uint64_t m, const uint8_t *V,
+                                    const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags) {
+    return guard([&] {
+        REQUIRE(ctx && c && ts && proof && seed && (m == 0 || V));
+        if (m != c->m) throw std::invalid_argument("verify: m does not match the uploaded circuit");
+        Transcript T = Transcript::from_state(ts);
+        const R1CSError e = ctx->engine->verify(c->dc, T, V, proof, proof_len, seed, flags);
+        T.export_state(ts);
+        if (e != R1CSError::None) throw R1CSException(e, e == R1CSError::VerificationError ? "proof rejected" : e == R1CSError::FormatError ? "malformed proof" : "generator capacity below padded circuit size");
+    });
+}
+
 // ---------------------------------------------------------------------------------------- transcript
 bpg_status bpg_transcript_new(const uint8_t *label, uint64_t len, bpg_transcript **out) {
     return guard([&] { REQUIRE(out && (len == 0 || label)); *out = new bpg_transcript{Transcript(label, len)}; });

@@ -97,6 +97,11 @@ uint64_t bpg_proof_size(uint64_t n_multipliers, uint32_t flags);
 bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
                            uint64_t m, const uint8_t *V, const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags);
 
+/* the same on an uploaded circuit (prover-side or verifier-side upload): a verifier that checks many proofs of one circuit
+ * keeps the constraint matrix in HBM. */
+bpg_status bpg_r1cs_verify_resident(bpg_ctx *ctx, bpg_circuit *circuit, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
+                                    uint64_t m, const uint8_t *V, const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags);
+
 /* measurement hooks (bench.py): HIP events on the engine's own stream. mode 0 off, 1 = dominant kernel only, 2 = all kernels;
  * report = JSON text {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}} accumulated since the last set. */
 bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);

@@ -52,6 +52,8 @@ def check_against_oracle(ctx, prover, transcript, commitments, capacity, replay=
         # the GPU verifier (bpg_r1cs_verify) must take the same decisions as the oracle verifier
         vinst = vi if replay is not None else inst
         assert ctx.verify_flat(vinst, vstate or state, coms, proof, flags=flags) == 0
+        assert res.verify(vstate or state, coms, proof, flags=flags) == 0           # same decision on the resident (prover-side) upload
+        assert res.verify(vstate or state, coms, proof[:40] + bytes([proof[40] ^ 1]) + proof[41:], flags=flags) in (2, 3)
         for pos in (5, 100, len(proof) - 40, len(proof) - 1):
             bad = bytearray(proof); bad[pos] ^= 0x01
             want = O.verify(ogens, vstate or state, vcirc or oc, coms, bytes(bad), flags=flags)
