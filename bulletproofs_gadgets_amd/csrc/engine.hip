@@ -134,6 +134,7 @@ struct Engine::Impl {
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
     PinBuf h_naf;
+    uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
@@ -153,6 +154,7 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
@@ -787,7 +789,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
-                if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
+                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory)
+                    BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
                 else if (nterms == 3 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
                 else if (nterms == 7 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
                 else if (nterms == 15 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);

@@ -582,6 +582,55 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (live) out[t] = ge_madd(acc, tab[i]);
 }
 
+// Latency variant of the same fold for small tables (2*Mr <= 64 K outputs: one wave per SIMD at most, so the kernel is one
+// dependent chain of 253 doublings + nterms * 84 additions whatever it does): the terms of an output are dealt to the FOUR
+// waves of a block (term q goes to wave q mod 4), each wave runs its own chain of doublings over its <= 4 addends with
+// wave-uniform digits, and the four partial sums meet in LDS.  4x the doublings, on hardware that would idle otherwise.
+__global__ void __launch_bounds__(256) k_fold_points_split(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H,
+                                                           ge_ext *__restrict__ out /* 2*Mr */, const uint32_t *__restrict__ naf, const FoldGroup fg) {
+    __shared__ ge_ext lds[256];
+    const uint32_t sub = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    uint32_t t = blockIdx.x * 64 + lane;
+    const bool live = t < 2 * fg.Mr;
+    if (!live) t = 2 * fg.Mr - 1;
+    const bool isH = t >= fg.Mr;
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const ge_niels *tab = isH ? H : G;
+    const uint32_t nslots = fg.nterms > sub ? (fg.nterms - sub + 3) / 4 : 0;          // terms q = sub + 4*j, j < nslots (<= 4)
+    ge_niels p0 = ge_niels_identity(), p1 = p0, p2 = p0, p3 = p0;
+    if (nslots > 0) p0 = tab[i + (size_t)(sub + 1) * fg.Mr];
+    if (nslots > 1) p1 = tab[i + (size_t)(sub + 5) * fg.Mr];
+    if (nslots > 2) p2 = tab[i + (size_t)(sub + 9) * fg.Mr];
+    if (nslots > 3) p3 = tab[i + (size_t)(sub + 13) * fg.Mr];
+    uint32_t bmask = 0;                                          // bit j: slot j is a padding generator for this lane
+    if (fg.first_group) for (uint32_t j = 0; j < nslots; j++) if (i + (size_t)(sub + 4 * j + 1) * fg.Mr >= fg.n) bmask |= 1u << j;
+    const uint32_t key = (isH ? 0x80000000u : 0u) | bmask;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    const bool uniform = __ballot(key != key0) == 0ull;
+    const uint32_t hsel = isH ? 2u : 0u;
+    ge_ext acc = ge_identity();
+    if (nslots) for (int k = fg.top; k >= 0; k--) {
+        acc = ge_dbl(acc);
+#pragma unroll 1
+        for (uint32_t j = 0; j < nslots; j++) {
+            const uint32_t q = sub + 4 * j;
+            const uint32_t cls = uniform ? (uint32_t)__builtin_amdgcn_readfirstlane(hsel + ((bmask >> j) & 1u)) : hsel + ((bmask >> j) & 1u);
+            const uint32_t *d = naf + ((size_t)cls * fg.nterms + q) * 16;
+            const uint32_t nz = (d[k >> 5] >> (k & 31)) & 1u, ng = (d[8 + (k >> 5)] >> (k & 31)) & 1u;
+            if (uniform ? (__builtin_amdgcn_readfirstlane(nz) != 0) : (nz != 0)) {
+                const ge_niels Q = j == 0 ? p0 : (j == 1 ? p1 : (j == 2 ? p2 : p3));
+                acc = ge_madd_signed(acc, Q, ng);
+            }
+        }
+    }
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    if (sub == 0 && live) {
+        ge_ext r = ge_add(ge_add(lds[lane], lds[64 + lane]), ge_add(lds[128 + lane], lds[192 + lane]));
+        out[t] = ge_madd(r, tab[i]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ verifier
 // compressed points -> affine Niels (Z = 1 after decoding, so no inversion); ok[i] = 0 for invalid encodings
 __global__ void __launch_bounds__(64) k_decompress(const uint8_t *__restrict__ in, ge_niels *__restrict__ out, uint32_t *__restrict__ ok, uint32_t count) {
