@@ -87,7 +87,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points)
 enum KernelId {
@@ -126,7 +126,7 @@ struct Engine::Impl {
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain;
     uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
@@ -185,7 +185,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release();
     (void)hipStreamDestroy(impl_->st);
@@ -362,12 +362,14 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, 1u << lgCH);
     heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
+    plain.ensure((size_t)(total ? total : 1) * 32);
+    if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(256), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
     BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
     BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(256), nb * 4, S, P, tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(256), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;

@@ -715,9 +715,18 @@ __device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, c
 #pragma unroll
     for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + P.bias[k] + carry; w[k] = (uint32_t)t; carry = t >> 32; }
 }
+// biased plain words of every term, once per MSM (the tile kernels run W times over the same scalars)
+__global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_t total, uint4 *__restrict__ plain) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
+    plain[2 * (size_t)g] = make_uint4(w[0], w[1], w[2], w[3]);
+    plain[2 * (size_t)g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
 template <int PASS>
-__global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, uint32_t *__restrict__ H, const uint32_t *__restrict__ starts,
-                                                  uint32_t *__restrict__ entries) {
+__global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
+                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
     extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
     const uint32_t T = blockIdx.x, win = blockIdx.y;
     uint32_t m = 0;
@@ -731,14 +740,19 @@ __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, uint32_t
     if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = 0;
     else for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
     __syncthreads();
+    // the window's bits sit in one or two of the eight words: read only the 16-byte half (or both halves) that holds them
+    const uint32_t off = msm_off(win, P.W), wd = msm_off(win + 1, P.W) - off, wi = off >> 5, sh = off & 31;
     for (uint32_t g = g0 + threadIdx.x; g < g1; g += 256) {
-        const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-        uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
-        const int32_t d = msm_digit_biased(w, P.W, win);
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(plain + 2 * (size_t)g);
+        const uint64_t two = (uint64_t)pw[wi] | ((uint64_t)(wi + 1 < 8 ? pw[wi + 1] : 0u) << 32);
+        const int32_t d = (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
         if (d == 0) continue;
         const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
         if (PASS == 0) atomicAdd(&tile_lds[mag - 1], 1u);
-        else { const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i; }
+        else {
+            const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+            const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i;
+        }
     }
     if (PASS == 0) {
         __syncthreads();
