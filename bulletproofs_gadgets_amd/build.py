@@ -7,6 +7,9 @@ PKG = pathlib.Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libbpg_hip.so"
 SOURCES = [CSRC / "engine.hip", CSRC / "capi.hip"]
+# native file drivers (reference src/bin/prover.rs, src/bin/verifier.rs) over the C ABI: one executable, two names
+CLI_SRC = CSRC / "cli_main.cpp"
+CLI_BINS = [PKG / "bin" / "bpg_prover", PKG / "bin" / "bpg_verifier"]
 
 
 def _deps():
@@ -24,8 +27,24 @@ def needs_build():
     return any(p.stat().st_mtime > t for p in _deps())
 
 
+def build_cli(verbose=False):
+    """g++ csrc/cli_main.cpp against include/bpg.h + libbpg_hip.so (rpath = the package directory)."""
+    if all(b.exists() and b.stat().st_mtime >= max(CLI_SRC.stat().st_mtime, LIB.stat().st_mtime) for b in CLI_BINS):
+        return CLI_BINS
+    CLI_BINS[0].parent.mkdir(exist_ok=True)
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", str(CLI_SRC), "-o", str(CLI_BINS[0]), "-L", str(PKG), "-lbpg_hip",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    import shutil
+    shutil.copy2(CLI_BINS[0], CLI_BINS[1])
+    return CLI_BINS
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        build_cli(verbose)
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
@@ -34,6 +53,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=str(CSRC))
+    build_cli(verbose)
     return LIB
 
 
