@@ -63,16 +63,6 @@ BPG_HD ge_ext ge_dbl(const ge_ext &p) {
     return r;
 }
 
-// doubling whose result only feeds another doubling: T is never read, 4S + 3M
-BPG_HD ge_ext ge_dbl_noT(const ge_ext &p) {
-    fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ2 = fe_sq(p.Z); ZZ2 = fe_add(ZZ2, ZZ2);
-    fe S = fe_sq(fe_add(p.X, p.Y));
-    fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
-    fe cX = fe_sub(S, YpX), cT = fe_sub(ZZ2, YmX);
-    ge_ext r; r.X = fe_mul(cX, cT); r.Y = fe_mul(YpX, YmX); r.Z = fe_mul(YmX, cT); r.T = p.T;
-    return r;
-}
-
 // projective Niels operand (Y+X, Y-X, Z, 2dT; 128 bytes): table entries that are never normalised (IPA tail tables)
 struct ge_pniels { fe ypx, ymx, Z, t2d; };
 BPG_HD ge_pniels ge_to_pniels(const ge_ext &p) {

@@ -1,12 +1,18 @@
 // HIP kernels of the Bulletproofs R1CS prove path for gfx950 (MI355X).  Integer VALU work (v_mad_u64_u32 chains);
 // no MFMA - this is 255-bit modular arithmetic, not a dense contraction.  Hot-path rows of SURVEY.md section 8(a):
 //   a7  BulletproofGens::new            k_gens_derive + k_normalize_niels
-//   a1-a3,a6  Pedersen commits          k_pedersen
-//   a9  A_I, A_O, S multiscalar muls    k_msm_* (bucket method: digit histogram -> scan -> scatter -> bucket sweep)
+//   a1-a3,a6  Pedersen commits          k_pedersen (window tables of B and B_blinding: k_tt_bases, k_tt_multiples)
+//   a9  A_I, A_O, S multiscalar muls    k_msm_plain, k_msm_tile<0/1>, k_msm_tile_prefix, k_scan_*, k_bucket_chunks, k_bucket_combine(_heavy),
+//                                       k_bucket_reduce, k_window_sums, k_msm_horner (bucket method: LDS tile histograms -> scan -> scatter ->
+//                                       balanced bucket sweep -> reductions)
 //   a10 vector-polynomial phase         k_exp_table, k_flatten, k_poly_t, k_poly_eval, k_reduce_partials
-//   a11 inner-product argument          k_ipa_prep, k_ipa_fold_scalars, k_fold_points (+ the MSM kernels)
+//   a11 inner-product argument          above 2^14 generators: k_ipa_prep, the MSM kernels, k_tt_advance, k_fold_points / k_fold_points_reg<NT> /
+//                                       k_fold_points_split once per group of rounds; below: k_tt_bases, k_tt_multiples, k_tt_factors, then
+//                                       k_tt_advance, k_tt_round, k_tt_finish per round
+//   f1  Verifier::verify                k_decompress, k_flatten_const, k_ipa_s, k_verify_scalars + one MSM
 // Data layout in HBM: scalars = 8 x u32 Montgomery form, 32 B each, AoS (lane i <-> element i: 2 x 16 B coalesced
-// loads); generator tables = affine Niels (y+x, y-x, 2dxy), 96 B per point, G at [0,N) and H at [N,2N).
+// loads); generator tables = affine Niels (y+x, y-x, 2dxy), 96 B per point, G at [0,N) and H at [N,2N); window tables =
+// projective Niels (y+x, y-x, z, 2dt), 128 B per entry.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ge.cuh"
