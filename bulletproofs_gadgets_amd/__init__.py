@@ -20,6 +20,7 @@ LIB_PATH = _PKG / "libbpg_hip.so"
 
 FLAG_COMPACT_1PHASE = 1
 FLAG_NO_1PHASE_DOMSEP = 2
+FLAG_EXPANDED_BLINDING = 4      # prover-only opt-in: s_L, s_R expanded from one TranscriptRng draw (include/bpg.h); not upstream's derivation
 VAR_MULTIPLIER_LEFT, VAR_MULTIPLIER_RIGHT, VAR_MULTIPLIER_OUTPUT, VAR_COMMITTED, VAR_ONE = 0, 1, 2, 3, 4
 L = 2**252 + 27742317777372353535851937790883648493
 

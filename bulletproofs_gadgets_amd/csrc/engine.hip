@@ -89,7 +89,7 @@ struct DeviceCircuit {
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -554,6 +554,13 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             nparts++;
         }
     };
+    if (flags & 4u) {   // BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): one draw K, the 2n scalars are expanded from it on the device
+        uint8_t msg[80]; std::memset(msg, 0, sizeof msg);
+        std::memcpy(msg, "bpg blinding v1", 15);
+        rng.fill_bytes(msg + 15, 64);
+        BlindHead head; std::memcpy(head.lane, msg, 80); head.lane[9] &= 0x00ffffffffffffffULL;      // byte 79 belongs to the index
+        if (n) BPG_LAUNCH(I, k_blind_expand, dim3(cdiv(2 * n, 256)), dim3(256), head, sL, (uint32_t)(2 * n));
+    } else
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
         uint8_t *raw = I.h_raw.as<uint8_t>();

@@ -158,6 +158,47 @@ __global__ void __launch_bounds__(256) k_sc_from_wide(const uint32_t *__restrict
     for (int k = 0; k < 4; k++) { uint4 q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
     out[i] = sc_from_wide_words(w);
 }
+// BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): scalar j = SHAKE256("bpg blinding v1" || K || le64(j))[0..64) mod l, one Keccak-f[1600]
+// per thread.  The 87 message bytes fill lanes 0..10: lanes 0..8 and the low 7 bytes of lane 9 are the same for every j (head[]).
+__device__ __forceinline__ uint64_t kk_rol(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+struct BlindHead { uint64_t lane[10]; };
+__global__ void __launch_bounds__(256) k_blind_expand(const BlindHead head, scm *__restrict__ out, uint32_t count) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    uint64_t a[25];
+#pragma unroll
+    for (int k = 0; k < 25; k++) a[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 10; k++) a[k] = head.lane[k];
+    a[9] |= (uint64_t)(j & 0xffu) << 56;                      // byte 79 = low byte of le64(j)
+    a[10] = (uint64_t)(j >> 8) | (0x1fULL << 56);             // bytes 80..86 = the rest of j, byte 87 = SHAKE padding
+    a[16] = 0x80ULL << 56;                                    // byte 135 = end of the 136-byte rate
+    const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL,
+        0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL, 0x8000000000008002ULL,
+        0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL, 0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL,
+        0x8000000080008008ULL};
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20], c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21], c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22],
+                 c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23], c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+        const uint64_t d0 = c4 ^ kk_rol(c1, 1), d1 = c0 ^ kk_rol(c2, 1), d2 = c1 ^ kk_rol(c3, 1), d3 = c2 ^ kk_rol(c4, 1), d4 = c3 ^ kk_rol(c0, 1);
+        const uint64_t b00 = a[0] ^ d0, b01 = kk_rol(a[6] ^ d1, 44), b02 = kk_rol(a[12] ^ d2, 43), b03 = kk_rol(a[18] ^ d3, 21), b04 = kk_rol(a[24] ^ d4, 14);
+        const uint64_t b05 = kk_rol(a[3] ^ d3, 28), b06 = kk_rol(a[9] ^ d4, 20), b07 = kk_rol(a[10] ^ d0, 3), b08 = kk_rol(a[16] ^ d1, 45), b09 = kk_rol(a[22] ^ d2, 61);
+        const uint64_t b10 = kk_rol(a[1] ^ d1, 1), b11 = kk_rol(a[7] ^ d2, 6), b12 = kk_rol(a[13] ^ d3, 25), b13 = kk_rol(a[19] ^ d4, 8), b14 = kk_rol(a[20] ^ d0, 18);
+        const uint64_t b15 = kk_rol(a[4] ^ d4, 27), b16 = kk_rol(a[5] ^ d0, 36), b17 = kk_rol(a[11] ^ d1, 10), b18 = kk_rol(a[17] ^ d2, 15), b19 = kk_rol(a[23] ^ d3, 56);
+        const uint64_t b20 = kk_rol(a[2] ^ d2, 62), b21 = kk_rol(a[8] ^ d3, 55), b22 = kk_rol(a[14] ^ d4, 39), b23 = kk_rol(a[15] ^ d0, 41), b24 = kk_rol(a[21] ^ d1, 2);
+        a[0] = b00 ^ (~b01 & b02) ^ RC[r]; a[1] = b01 ^ (~b02 & b03); a[2] = b02 ^ (~b03 & b04); a[3] = b03 ^ (~b04 & b00); a[4] = b04 ^ (~b00 & b01);
+        a[5] = b05 ^ (~b06 & b07); a[6] = b06 ^ (~b07 & b08); a[7] = b07 ^ (~b08 & b09); a[8] = b08 ^ (~b09 & b05); a[9] = b09 ^ (~b05 & b06);
+        a[10] = b10 ^ (~b11 & b12); a[11] = b11 ^ (~b12 & b13); a[12] = b12 ^ (~b13 & b14); a[13] = b13 ^ (~b14 & b10); a[14] = b14 ^ (~b10 & b11);
+        a[15] = b15 ^ (~b16 & b17); a[16] = b16 ^ (~b17 & b18); a[17] = b17 ^ (~b18 & b19); a[18] = b18 ^ (~b19 & b15); a[19] = b19 ^ (~b15 & b16);
+        a[20] = b20 ^ (~b21 & b22); a[21] = b21 ^ (~b22 & b23); a[22] = b22 ^ (~b23 & b24); a[23] = b23 ^ (~b24 & b20); a[24] = b24 ^ (~b20 & b21);
+    }
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { w[2 * k] = (uint32_t)a[k]; w[2 * k + 1] = (uint32_t)(a[k] >> 32); }
+    out[j] = sc_from_wide_words(w);
+}
 __global__ void __launch_bounds__(256) k_sc_to_bytes(const scm *__restrict__ in, uint32_t *__restrict__ out, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

@@ -33,6 +33,12 @@ typedef int32_t bpg_status;
 /* dialect flags of the proof encoding / transcript (the fork's revision is unpinned) */
 #define BPG_FLAG_COMPACT_1PHASE 1u            /* v2.0.0 encoding: version byte 0x00 + 11 points */
 #define BPG_FLAG_NO_1PHASE_DOMSEP 2u          /* omit the "r1cs-1phase" domain separator */
+/* Prover-only, opt-in, NOT upstream's derivation (off by default; never used for the headline benchmark): the 2n blinding scalars
+ * s_L || s_R are expanded on the GPU instead of being drawn one by one from Merlin's serial TranscriptRng (which is 87 % of a
+ * 2^20 proof).  After the three blinding scalars of A_I, A_O, S one more 64-byte block K is drawn from the TranscriptRng; scalar j is
+ * from_bytes_mod_order_wide(SHAKE256("bpg blinding v1" || K || le64(j))[0..64)).  K depends on the transcript, the witness blindings
+ * and the external 32 random bytes exactly as every upstream draw does.  The proof is an ordinary proof for any verifier. */
+#define BPG_FLAG_EXPANDED_BLINDING 4u
 
 /* variable encoding inside constraint terms: kind << 29 | index   (bulletproofs::r1cs::Variable) */
 #define BPG_VAR_MULTIPLIER_LEFT 0u

@@ -27,6 +27,7 @@
 /* dialect flags; shared numbering with include/bpg.h */
 #define ORC_FLAG_COMPACT_1PHASE 1u  /* v2.0.0 encoding: version byte + 11 points */
 #define ORC_FLAG_NO_1PHASE_DOMSEP 2u
+#define ORC_FLAG_EXPANDED_BLINDING 4u /* NOT upstream: s_L, s_R = SHAKE256("bpg blinding v1" || K || le64(j)) with K one TranscriptRng draw (include/bpg.h) */
 #define ORC_FLAG_FAST_MSM 0x100u    /* oracle-only: Pippenger instead of upstream's constant-time Straus (same group elements) */
 
 /* variable encoding inside constraint terms: kind << 29 | index */

@@ -242,8 +242,23 @@ int orc_r1cs_prove(const orc_gens *g, uint8_t tstate[203], const orc_circuit *c,
     sc ib, ob, sb;
     merlin_rng_scalar(&rng, &ib); merlin_rng_scalar(&rng, &ob); merlin_rng_scalar(&rng, &sb);
     sc *sL = (sc *)malloc(N * sizeof(sc)), *sR = (sc *)malloc(N * sizeof(sc));
-    for (size_t i = 0; i < n; i++) merlin_rng_scalar(&rng, &sL[i]);
-    for (size_t i = 0; i < n; i++) merlin_rng_scalar(&rng, &sR[i]);
+    if (flags & ORC_FLAG_EXPANDED_BLINDING) {
+        /* opt-in dialect of the product (include/bpg.h BPG_FLAG_EXPANDED_BLINDING), restated independently: one 64-byte draw K,
+         * then scalar j of s_L || s_R is SHAKE256("bpg blinding v1" || K || le64(j)) read as 64 bytes and reduced mod l */
+        uint8_t K[64]; merlin_rng_fill(&rng, K, 64);
+        for (size_t j = 0; j < 2 * n; j++) {
+            shake256_ctx sh; shake256_init(&sh);
+            shake256_absorb(&sh, (const uint8_t *)"bpg blinding v1", 15);
+            shake256_absorb(&sh, K, 64);
+            uint8_t idx[8]; for (int b = 0; b < 8; b++) idx[b] = (uint8_t)((uint64_t)j >> (8 * b));
+            shake256_absorb(&sh, idx, 8);
+            uint8_t wide[64]; shake256_squeeze(&sh, wide, 64);
+            sc_frombytes_wide(j < n ? &sL[j] : &sR[j - n], wide);
+        }
+    } else {
+        for (size_t i = 0; i < n; i++) merlin_rng_scalar(&rng, &sL[i]);
+        for (size_t i = 0; i < n; i++) merlin_rng_scalar(&rng, &sR[i]);
+    }
 
     /* A_I, A_O, S */
     sc *ms = (sc *)malloc((2 * N + 2) * sizeof(sc)); ge *mp = (ge *)malloc((2 * N + 2) * sizeof(ge));

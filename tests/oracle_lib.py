@@ -10,6 +10,7 @@ LIB = ROOT / "oracle" / "build" / "liboracle.so"
 
 FLAG_COMPACT_1PHASE = 1
 FLAG_NO_1PHASE_DOMSEP = 2
+FLAG_EXPANDED_BLINDING = 4      # prover-only opt-in: s_L, s_R expanded from one TranscriptRng draw (include/bpg.h); not upstream's derivation
 FLAG_FAST_MSM = 0x100
 OK, ERR_GENS_LENGTH, ERR_FORMAT, ERR_VERIFY, ERR_ARG = 0, 1, 2, 3, 4
 

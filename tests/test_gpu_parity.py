@@ -449,3 +449,27 @@ def test_fold_group_sizes_above_the_tail(ctx, blocks, N):
     rc, want, st_want = O.prove(og, a.transcript.state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
     assert rc == 0 and proof == want and st_after == st_want
     res.free()
+
+
+def test_expanded_blinding_dialect_matches_oracle_and_verifies(ctx):
+    """BPG_FLAG_EXPANDED_BLINDING (opt-in, not upstream's derivation of s_L, s_R): same bytes as the oracle's independent
+    restatement (SHAKE256 over one TranscriptRng draw), accepted by both verifiers, different from the default dialect."""
+    for maker in (lambda: workloads.bounds_check_64(ctx, seed=5), lambda: workloads.mimc_preimage(ctx, nbytes=70, seed=9, label=b"MiMCHash")):
+        a = maker()
+        inst = a.prover.instance()
+        state = a.transcript.state
+        ctx.gens_ensure(a.gens_capacity)
+        og = O.Gens(a.gens_capacity)
+        res = ctx.upload(inst)
+        base, _ = res.prove(state, inst.v_blinding, bytes(range(32)), 0)
+        for flags in (bpg.FLAG_EXPANDED_BLINDING, bpg.FLAG_EXPANDED_BLINDING | bpg.FLAG_COMPACT_1PHASE):
+            proof, st_after = res.prove(state, inst.v_blinding, bytes(range(32)), flags)
+            rc, want, st_want = O.prove(og, state, to_oracle(inst), inst.v_blinding, bytes(range(32)), flags | O.FLAG_FAST_MSM)
+            assert rc == 0 and proof == want and st_after == st_want
+            enc = flags & 3                                        # the verifier only needs the encoding dialect
+            coms = b"".join(a.commitments)
+            assert O.verify(og, state, to_oracle(inst), coms, proof, flags=enc) == 0
+            assert res.verify(state, coms, proof, flags=enc) == 0
+            assert res.verify(state, coms, proof, flags=flags) == 0       # and ignores the prover-only bit
+        assert proof != base
+        res.free()
