@@ -522,7 +522,8 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
 
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
-    {
+    const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind, one MSM pass for A_I, A_O, S
+    if (!expanded) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
         seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
@@ -554,12 +555,22 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             nparts++;
         }
     };
-    if (flags & 4u) {   // BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): one draw K, the 2n scalars are expanded from it on the device
+    if (expanded) {     // (include/bpg.h): one draw K, the 2n scalars are expanded from it on the device
         uint8_t msg[80]; std::memset(msg, 0, sizeof msg);
         std::memcpy(msg, "bpg blinding v1", 15);
         rng.fill_bytes(msg + 15, 64);
         BlindHead head; std::memcpy(head.lane, msg, 80); head.lane[9] &= 0x00ffffffffffffffULL;      // byte 79 belongs to the index
         if (n) BPG_LAUNCH(I, k_blind_expand, dim3(cdiv(2 * n, 256)), dim3(256), head, sL, (uint32_t)(2 * n));
+        MsmSegs S = seg_new();
+        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
+        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
+        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
+        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
+        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+        seg_push(S, sL, Gtab, (uint32_t)n, 2);
+        seg_push(S, sR, Htab, (uint32_t)n, 2);
+        seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
+        I.msm(S, 3, I.msm_result.as<ge_ext>());
     } else
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
@@ -575,8 +586,10 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
-    launch_pieces(2 * n);
-    BPG_LAUNCH(I, k_sum_points, dim3(1), dim3(64), I.s_parts.as<ge_ext>(), nparts, I.msm_result.as<ge_ext>() + 2);
+    if (!expanded) {
+        launch_pieces(2 * n);
+        BPG_LAUNCH(I, k_sum_points, dim3(1), dim3(64), I.s_parts.as<ge_ext>(), nparts, I.msm_result.as<ge_ext>() + 2);
+    }
     BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
     HIPCHK(hipGetLastError());
     uint8_t pts[96];
