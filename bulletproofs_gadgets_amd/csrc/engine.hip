@@ -522,8 +522,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
 
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
-    const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind, one MSM pass for A_I, A_O, S
-    if (!expanded) {
+    const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind
+    const bool merged = expanded || n < 4096;         // nothing worth hiding: one MSM pass for A_I, A_O, S after the draws (one serial tail, not three)
+    if (!merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
         seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
@@ -540,6 +541,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     // the first 7/8 of <s_R, H> next, and only the last eighth (+ the blinding term) after the chain has ended.
     I.s_parts.ensure(4 * sizeof(ge_ext));
     struct Piece { uint64_t a, b; } pieces[3] = {{0, n}, {n, n + (n - n / 8)}, {n + (n - n / 8), 2 * n}};
+    if (n < (1u << 17)) { pieces[0] = {0, 0}; pieces[1] = {0, 0}; pieces[2] = {0, 2 * n}; }      // short chain: one MSM after it (each call has a ~1 ms serial tail)
     uint32_t next_piece = 0, nparts = 0;
     auto launch_pieces = [&](uint64_t drawn) {
         while (next_piece < 3 && pieces[next_piece].b <= drawn) {
@@ -561,16 +563,6 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         rng.fill_bytes(msg + 15, 64);
         BlindHead head; std::memcpy(head.lane, msg, 80); head.lane[9] &= 0x00ffffffffffffffULL;      // byte 79 belongs to the index
         if (n) BPG_LAUNCH(I, k_blind_expand, dim3(cdiv(2 * n, 256)), dim3(256), head, sL, (uint32_t)(2 * n));
-        MsmSegs S = seg_new();
-        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
-        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
-        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
-        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
-        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
-        seg_push(S, sL, Gtab, (uint32_t)n, 2);
-        seg_push(S, sR, Htab, (uint32_t)n, 2);
-        seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
-        I.msm(S, 3, I.msm_result.as<ge_ext>());
     } else
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
@@ -581,12 +573,23 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             rng.fill_draws64(raw + 64 * i, cnt);
             HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
             BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
-            if (i + cnt < 2 * n) launch_pieces(i + cnt);
+            if (!merged && i + cnt < 2 * n) launch_pieces(i + cnt);
         }
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
-    if (!expanded) {
+    if (merged) {
+        MsmSegs S = seg_new();
+        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
+        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
+        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
+        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
+        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+        seg_push(S, sL, Gtab, (uint32_t)n, 2);
+        seg_push(S, sR, Htab, (uint32_t)n, 2);
+        seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
+        I.msm(S, 3, I.msm_result.as<ge_ext>());
+    } else {
         launch_pieces(2 * n);
         BPG_LAUNCH(I, k_sum_points, dim3(1), dim3(64), I.s_parts.as<ge_ext>(), nparts, I.msm_result.as<ge_ext>() + 2);
     }

@@ -1,0 +1,22 @@
+"""prove / verify times of the small BASELINE.json configurations (parity cases, not bench lines)"""
+import sys, time
+sys.path.insert(0, "/root/repo")
+import bulletproofs_gadgets_amd as bpg
+from bulletproofs_gadgets_amd import workloads
+ctx = bpg.Context(0)
+for name, mk in (("cfg2 bounds_check_64", lambda: workloads.bounds_check_64(ctx, seed=0)),
+                 ("cfg3 mimc_preimage 2^16", lambda: workloads.mimc_preimage(ctx, nbytes=2130, seed=0, label=b"MiMCHash")),
+                 ("32-leaf merkle 2^16", lambda: workloads.merkle_full_tree(ctx, leaves=32, seed=7))):
+    a = mk(); inst = a.prover.instance(); state = a.transcript.state
+    ctx.gens_ensure(a.gens_capacity); res = ctx.upload(inst)
+    res.prove(state, inst.v_blinding, bytes(32), 0)
+    t0 = time.perf_counter()
+    for i in range(5): proof, _ = res.prove(state, inst.v_blinding, bytes([i]) * 32, 0)
+    dt = (time.perf_counter() - t0) / 5
+    _, _, tm = res.prove(state, inst.v_blinding, bytes(32), 0, timings=True)
+    coms = b"".join(a.commitments)
+    t0 = time.perf_counter()
+    for i in range(5): ok = res.verify(state, coms, proof)
+    dv = (time.perf_counter() - t0) / 5
+    print("%-26s n=%d N=%d q=%d: prove %.2f ms (%.0f constraints/s; rng %.2f ipa %.2f)  verify %.2f ms ok=%s" % (name, inst.n, a.gens_capacity, inst.q, dt * 1e3, inst.q / dt, tm["rng_host"], tm["ipa"], dv * 1e3, ok == 0), flush=True)
+    res.free()
