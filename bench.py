@@ -107,10 +107,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # BPG_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks then share devices and the proof bytes
+    # travel over gloo on CPU tensors); the driver's runs use the default: one rank per GPU, RCCL ("nccl")
+    backend = os.environ.get("BPG_BENCH_BACKEND", "nccl")
+    coll_device = "cuda" if backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()
+        if backend != "nccl" and ndev:
+            local_rank %= ndev
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     else:
         dist = None
     if not torch.cuda.is_available():
@@ -149,7 +159,7 @@ def main():
     def step(i, timings=False):
         out = res.prove(state, inst.v_blinding, seed_for(i), 0, timings=timings)
         if dist is not None:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
-            proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device="cuda")
+            proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
             assert len(proofs) == world
         return out
 
@@ -168,10 +178,10 @@ def main():
     prof = ctx.profile_report()
     ctx.profile_set(0)
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        qq = torch.tensor([float(inst.q)], dtype=torch.float64, device="cuda")
+        qq = torch.tensor([float(inst.q)], dtype=torch.float64, device=coll_device)
         dist.all_reduce(qq, op=dist.ReduceOp.SUM)
         q_total = float(qq.item())
     else:
