@@ -417,7 +417,7 @@ class Prover:
 
 
 class Verifier:
-    """bulletproofs::r1cs::Verifier::new(&mut transcript): assembly side only (verification equation: oracle / next round)."""
+    """bulletproofs::r1cs::Verifier::new(&mut transcript): constraint assembly on the host, verify() / is_valid() on the GPU (bpg_verifier_verify)."""
 
     def __init__(self, transcript: Transcript):
         self.transcript = transcript
