@@ -130,37 +130,66 @@ def test_set_membership(ctx, member, ok):
     run(ctx, b"SetMembership", bp, bv, 8, ok)
 
 
-def test_or_conjunction_of_hash_clauses(ctx):
-    """reference src/or/or_conjunction.rs:84-190: three MiMC preimage clauses, only some of them true; the disjunction verifies
-    iff at least one clause holds. (Small images here: 1-block preimages -> 1,946 constraints per clause.)"""
-    pre = [b"alpha", b"beta", b"gamma"]
+OR_PRE = [H("38535450433043546f313877615a6a423663"),
+          H("54686520717569" "4a76077d4a40bd91551b3a03b1ad8adb2b" "666f78206a756d70" "666f78206a756d70" "73206f7665"),
+          H("54686520717569636b2062726f776e20666f78206a756d7073206f7665722074")]
+OR_IMG = [H("0d2203069ac15f58172bae1b3af98d8982deef9df37482c1a920b8832ee813a4"),
+          H("0fcb21fbf23b968dee8f6b3a511e93e8c5c0eb2f71aa0601111f911c9e42cf06"),
+          H("01245409f28ae2f076077d4a40bd91551b3a03b1ad8adb2b1da116d29c60a85c")]
 
-    def build(claims_true):
-        images = [bpg.mimc_hash(x) if t else bpg.mimc_hash(x + b"!") for x, t in zip(pre, claims_true)]
 
-        def bp(p):
-            buf = bpg.ConstraintBuffer(p, True)
-            coms = []
-            for k, (x, img) in enumerate(zip(pre, images)):
-                g = bpg.MimcHash256(img)
-                sc_, wc, wv = bpg.commit(p, x, [rs(b"or%d" % k, 0)])
-                dc, dw = g.setup(p, sc_, [rs(b"or%d" % k, 1), rs(b"or%d" % k, 2)])
-                g.prove(buf, wv, dw)
-                buf.rewind()
-                coms += wc + dc
-            bpg.or_conjunction(p, buf)
-            return coms
+def _or_hash_builders(pre, images):
+    """three MimcHash256 clauses recorded in a ConstraintBuffer, then or() into the main prover / verifier"""
+    widths = [len(bpg.be_to_scalars(x)) for x in pre]
+    layout = {}                                       # clause -> number of commitments (witness scalars + derived)
 
-        def bv(v, coms):
-            buf = bpg.ConstraintBuffer(v, False)
-            vs = bpg.verifier_commit(v, coms)
-            for k, img in enumerate(images):
-                bpg.MimcHash256(img).verify(buf, [vs[3 * k]], vs[3 * k + 1:3 * k + 3])
-                buf.rewind()
-            bpg.or_conjunction(v, buf)
-        return bp, bv
-    # 3 clauses x 1,946 constraints would give 7.4e9 products; use two clauses (3.8 M products) only for the true/false matrix on
-    # a smaller gadget: BOUND (35 constraints) x BOUND x BOUND = 42,875 products
+    def bp(p):
+        buf = bpg.ConstraintBuffer(p, True)
+        coms = []
+        for k, (x, img) in enumerate(zip(pre, images)):
+            g = bpg.MimcHash256(bpg.be_to_scalar(img))
+            sc_, wc, wv = bpg.commit(p, x, [rs(b"or%d" % k, j) for j in range(widths[k])])
+            dc, dw = g.setup(p, sc_, [rs(b"or%d" % k, 10), rs(b"or%d" % k, 11)])
+            g.prove(buf, wv, dw)
+            buf.rewind()
+            layout[k] = len(wc) + len(dc)
+            coms += wc + dc
+        bpg.or_conjunction(p, buf)
+        return coms
+
+    def bv(v, coms):
+        buf = bpg.ConstraintBuffer(v, False)
+        vs = bpg.verifier_commit(v, coms)
+        pos = 0
+        for k, img in enumerate(images):
+            bpg.MimcHash256(bpg.be_to_scalar(img)).verify(buf, vs[pos:pos + widths[k]], vs[pos + widths[k]:pos + layout[k]])
+            pos += layout[k]
+            buf.rewind()
+        bpg.or_conjunction(v, buf)
+    return bp, bv
+
+
+def test_or_conjunction_reference_vectors(ctx):
+    """reference src/or/or_conjunction.rs:84-190 (test_or_conjunction_1): three MimcHash256 clauses over the reference's preimages and
+    images, 8192 generators; the disjunction verifies.  Each clause contributes 2 explicit constraints (the other 1944+ come from
+    multiply), so or() adds 2*2*2 products of two multipliers each."""
+    bp, bv = _or_hash_builders(OR_PRE, OR_IMG)
+    truth = [bpg.mimc_hash(x) == bpg.be_to_scalar(i) for x, i in zip(OR_PRE, OR_IMG)]
+    assert any(truth)
+    run(ctx, b"MiMCHash", bp, bv, 8192, True)
+    # every image wrong: no clause holds, the proof must not verify
+    wrong = [bytes([i[0] ^ 1]) + i[1:] for i in OR_IMG]
+    bp, bv = _or_hash_builders(OR_PRE, wrong)
+    run(ctx, b"MiMCHash", bp, bv, 8192, False)
+    # exactly one true clause, in each position
+    for k in range(3):
+        imgs = [bpg.scalar_to_be(bpg.mimc_hash(x)) if j == k else wrong[j] for j, x in enumerate(OR_PRE)]
+        bp, bv = _or_hash_builders(OR_PRE, imgs)
+        run(ctx, b"MiMCHash", bp, bv, 8192, True)
+
+
+def test_or_conjunction_of_bounds_clauses(ctx):
+    """true / false matrix on a gadget with many explicit constraints per clause: BOUND (35) x BOUND = 1,225 products"""
     lo, hi = bytes([10]), bytes([100])
 
     def build_bounds(values):
