@@ -111,6 +111,29 @@ def test_less_than(ctx, left, right, ok):
     run(ctx, b"LessThan", bp, bv, 512, ok)
 
 
+LT_A, LT_B = H("0522a64d7b931e21760cf955a15fcc"), H("aa22a64d7b931e21760cf955a15fcc")
+LT_MAX, LT_MAXM1 = H("3f" + "ff" * 15), H("3f" + "ff" * 14 + "fe")
+
+
+@pytest.mark.parametrize("left,right,ok", [(LT_A, LT_B, True), (LT_B, LT_A, False), (LT_MAXM1, LT_MAX, True), (LT_MAX, LT_MAXM1, False),
+                                           (b"\x00", b"\x00", False), (LT_MAX, LT_MAX, False)])
+def test_less_than_reference_vectors(ctx, left, right, ok):
+    """src/less_than/less_than_gadget.rs:96-333 (test_less_than_gadget_1..6): both sides are CONSTANT linear combinations
+    (Scalar::into()), no witness commitments, 1024 generators; cases 2, 4, 5, 6 must not verify."""
+    ls, rsc = bpg.be_to_scalar(left), bpg.be_to_scalar(right)
+
+    def bp(p):
+        g = bpg.LessThan(ls, ls, rsc, rsc)
+        dc, dw = g.setup(p, [], [rs(b"ltr", 2), rs(b"ltr", 3)])
+        g.prove(p, [], dw)
+        return dc
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        bpg.LessThan(ls, None, rsc, None).verify(v, [], vs)
+    run(ctx, b"LessThan", bp, bv, 1024, ok)
+
+
 @pytest.mark.parametrize("member,ok", [(b"\x43", True), (b"\x11", True), (b"\x64", True), (b"\x44", False)])
 def test_set_membership(ctx, member, ok):
     inst_set = [bpg.be_to_scalar(b"\x11"), bpg.be_to_scalar(b"\x64")]       # example.gadgets:8 style: instances and witnesses mixed
