@@ -153,6 +153,38 @@ def test_set_membership(ctx, member, ok):
     run(ctx, b"SetMembership", bp, bv, 8, ok)
 
 
+SM_V = [None, H("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb668749"), H("07faf8aaa21077200a11576b1cdb402f52a47f192b36998b4da25807a9be52f5"),
+        H("09243333e374e76e4975ab48ae38241ba67805cd60f1523e9b79a48daac9a84d"), H("0258647e47e8005748d4e7d0d76b230cc20f2a0f8745eee2bccced0c2add59d5"),
+        H("011c6fc7f15087f4d3e97e672813af066f74f60446bc75aa85eb2d6db8ae791b")]
+Z = b"\x00"
+
+
+@pytest.mark.parametrize("member,wit_set,inst_set,ok", [
+    (SM_V[1], [], [SM_V[4], SM_V[3], SM_V[1], SM_V[5], SM_V[2]], True),              # 1: set of instance variables
+    (SM_V[1], [SM_V[3], SM_V[5], SM_V[1]], [SM_V[4], SM_V[2]], True),                # 2: mixed set
+    (SM_V[1], [SM_V[3], SM_V[5]], [SM_V[4], SM_V[2]], False),                        # 3: mixed set, the value is not a member
+    (SM_V[1], [SM_V[3], SM_V[5], Z, SM_V[2]], [SM_V[4], SM_V[2]], False),            # 4: mixed set, a witness is 0 (and the value absent)
+    (SM_V[1], [SM_V[3], SM_V[1], SM_V[5]], [SM_V[4], SM_V[2], SM_V[1]], False),      # 5: the value is contained twice (the reference rejects: two indicator bits)
+    (Z, [SM_V[3], SM_V[5], Z, SM_V[1]], [SM_V[4], SM_V[2]], True)])                  # 6: zero member
+def test_set_membership_reference_vectors(ctx, member, wit_set, inst_set, ok):
+    """src/set_membership/set_membership_gadget.rs:174-403 (test_set_membership_gadget_1..6) with the reference's VALUE1..5, 64 generators."""
+    inst_sc = [bpg.be_to_scalar(x) for x in inst_set]
+
+    def bp(p):
+        ms, mc, mv = bpg.commit_single(p, member, rs(b"smr", 0))
+        ws, wc, wv = bpg.commit_all_single(p, wit_set, [rs(b"smr", 1 + i) for i in range(len(wit_set))]) if wit_set else ([], [], [])
+        g = bpg.SetMembership(mv, ms, inst_sc, inst_sc)
+        dc, dw = g.setup(p, ws, [rs(b"smd", i) for i in range(len(wit_set) + len(inst_set))])
+        g.prove(p, wv, dw)
+        return [mc] + wc + dc
+
+    def bv(v, coms):
+        vs = bpg.verifier_commit(v, coms)
+        k = len(wit_set)
+        bpg.SetMembership(vs[0], None, inst_sc, None).verify(v, vs[1:1 + k], vs[1 + k:])
+    run(ctx, b"SetMembership", bp, bv, 64, ok)
+
+
 OR_PRE = [H("38535450433043546f313877615a6a423663"),
           H("54686520717569" "4a76077d4a40bd91551b3a03b1ad8adb2b" "666f78206a756d70" "666f78206a756d70" "73206f7665"),
           H("54686520717569636b2062726f776e20666f78206a756d7073206f7665722074")]
