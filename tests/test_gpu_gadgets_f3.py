@@ -74,7 +74,16 @@ def test_equality_witness_right_hand(ctx):
 
 
 @pytest.mark.parametrize("left,right,ok", [(W_A, W_A[:-1] + b"\x48", True), (W_A, W_A, False), (LONG, LONG[:69] + b"\x00", True), (LONG, LONG, False),
-                                           (b"\x05", b"\x07", True), (b"\x07", b"\x05", True)])
+                                           (b"\x05", b"\x07", True), (b"\x07", b"\x05", True)] + [
+    # src/inequality/inequality_gadget.rs:126-419 (test_inequality_gadget_1..7): (left_assignment, right, verdict)
+    (H("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb668749" * 2 + "0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8ceb668749"),
+     H("0522a64d7b931e21760cf955a15fcc733e8a52b42a56ab03afddec8beb668749" "0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab02afddec8beb668749"
+       "0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8ceb668749"), True),
+    (W_A, H("0522a64d7b931e21760cf955a15fcc733e8a52b42a56ab03afddec8beb668749"), True),
+    (W_A[:31], b"\xff" * 32, True), (b"\xff" * 32, W_A[:31], True),
+    (H("0522a64d7b931e21760cf955a15fcc733e8a52b42a56ab03afddec8beb668749"), H("0522a64d7b931e21760cf955a15fcc733e8a52b42a56ab03afddec8beb668749"), False),
+    (H("0522a64d7b931e213e8a52b42a56ab030522a64d7b931e213e8a52b42a56ab03760cf955a15fcc790522a64d7b931e"), W_A[:31], True),
+    (W_A[:31], H("0522a64d7b931e213e8a52b42a56ab030522a64d7b931e213e8a52b42a56ab03760cf955a15fcc790522a64d7b931e"), True)])
 def test_inequality(ctx, left, right, ok):
     right_scalars = bpg.be_to_scalars(right)
 
