@@ -47,7 +47,12 @@ LONG = bytes(range(1, 71))          # 70 bytes -> 3 scalars
 
 
 @pytest.mark.parametrize("left,right,ok", [(W_A, W_A, True), (W_A, W_A[:-1] + b"\x48", False), (LONG, LONG, True),
-                                           (LONG, LONG[:40] + b"\xff" + LONG[41:], False), (LONG, LONG[:33], False)])
+                                           (LONG, LONG[:40] + b"\xff" + LONG[41:], False), (LONG, LONG[:33], False),
+                                           # src/equality/equality_gadget.rs:52-197 (test_equality_gadget_1..4), (left, right, verdict); 1 = the first case above
+                                           (H("0522a64d7b931e21760cf95aa15fcc793e8a52b42a56ab03afddec8beb668749"), W_A, False),
+                                           (H("0522a64d7b931e21"), W_A, False),
+                                           (H("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb6687493e8a52032a56ab03afddec8beb668749"),
+                                            H("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb6687493e8a52032a56ab03afddec8beb668749"), True)])
 def test_equality_instance_right_hand(ctx, left, right, ok):
     def bp(p):
         self_ = {}
