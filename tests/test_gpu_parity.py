@@ -244,9 +244,10 @@ def test_cfg2_bounds_check_64(ctx):
 
 
 @pytest.mark.parametrize("pre,label", [(H("38535450433043546f313877615a6a423663"), b"MiMCHash"),
-                                        (b"The quick brown fox jumps over t", b"MiMCHash")])
+                                        (b"The quick brown fox jumps over t", b"MiMCHash"),
+                                        (H("546865207175694a76077d4a40bd91551b3a03b1ad8adb2b666f78206a756d70666f78206a756d7073206f7665"), b"MiMCHash")])
 def test_mimc_hash_gadget_reference_cases(ctx, pre, label):
-    # reference src/mimc_hash/mimc_hash_gadget.rs:163-272 (happy padding case and the extra-block edge case)
+    # reference src/mimc_hash/mimc_hash_gadget.rs:163-272 (test_mimc_hash_gadget_1..3: padding case, extra-block edge case, 45-byte preimage)
     image = bpg.mimc_hash(pre)
     t = LabeledTranscript(label)
     p = bpg.Prover(ctx, t)
