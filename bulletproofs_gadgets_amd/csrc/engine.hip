@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include "engine.hpp"
 #include "hip/kernels.cuh"
 
@@ -252,12 +254,28 @@ void Engine::gens_ensure(uint64_t capacity) {
     // a serial XOF), then 2*capacity Elligator maps + one batched normalisation on the device.
     const uint64_t cap = capacity;
     I.h_raw.ensure(2 * cap * 64);
-    for (int which = 0; which < 2; which++) {
-        Shake256 sh;
-        const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
-        sh.absorb(reinterpret_cast<const uint8_t *>("GeneratorsChain"), 15);
-        sh.absorb(label, 5);
-        sh.squeeze(I.h_raw.as<uint8_t>() + (size_t)which * cap * 64, cap * 64);
+    {   // the two chains are independent XOF streams: squeeze them on two threads; the streams are prefixes of one another across
+        // capacities, so a process-wide cache keeps the longest one squeezed so far (contexts of a batch share it)
+        struct Chain { Shake256 sh; std::vector<uint8_t> bytes; bool started = false; };
+        static Chain chains[2];
+        static std::mutex chain_mutex;
+        std::lock_guard<std::mutex> lock(chain_mutex);
+        auto extend = [&](int which) {
+            Chain &c = chains[which];
+            if (!c.started) {
+                const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
+                c.sh.absorb(reinterpret_cast<const uint8_t *>("GeneratorsChain"), 15);
+                c.sh.absorb(label, 5);
+                c.started = true;
+            }
+            const size_t have = c.bytes.size(), want = (size_t)cap * 64;
+            if (want > have) { c.bytes.resize(want); c.sh.squeeze(c.bytes.data() + have, want - have); }
+        };
+        (void)keccak_impl();                                  // calibrate once before the threads start
+        std::thread th([&] { extend(1); });
+        extend(0);
+        th.join();
+        for (int which = 0; which < 2; which++) std::memcpy(I.h_raw.as<uint8_t>() + (size_t)which * cap * 64, chains[which].bytes.data(), (size_t)cap * 64);
     }
     I.raw_rng.ensure(2 * cap * 64);
     I.scratch_ext.ensure(2 * cap * sizeof(ge_ext));

@@ -226,7 +226,12 @@ public:
     void squeeze(uint8_t *out, size_t n) {
         uint8_t *b = bytes();
         if (!squeezing_) { b[pos_] ^= 0x1f; b[135] ^= 0x80; keccak_f1600_host(st_); pos_ = 0; squeezing_ = true; }
-        for (size_t i = 0; i < n; i++) { if (pos_ == 136) { keccak_f1600_host(st_); pos_ = 0; } out[i] = b[pos_++]; }
+        while (n) {                                           // whole-block copies: the generator chains squeeze 64 bytes per generator
+            if (pos_ == 136) { keccak_f1600_host(st_); pos_ = 0; }
+            const size_t take = n < 136 - pos_ ? n : 136 - pos_;
+            std::memcpy(out, b + pos_, take);
+            out += take; pos_ += take; n -= take;
+        }
     }
 private:
     uint8_t *bytes() { return reinterpret_cast<uint8_t *>(st_); }
