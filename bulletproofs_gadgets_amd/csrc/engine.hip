@@ -714,7 +714,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             I.tt_table.ensure((size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
             I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
             I.tt_partial.ensure((size_t)2 * cdiv((uint64_t)M0 * 8, 256) * sizeof(ge_ext));
-            BPG_LAUNCH(I, k_tt_bases, dim3(cdiv(npts, 256)), dim3(256), Gst, Hst, Bn, I.tt_bases.as<ge_ext>(), M0);
+            BPG_LAUNCH(I, k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), Gst, Hst, Bn, I.tt_bases.as<ge_ext>(), M0);
             BPG_LAUNCH(I, k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), I.tt_bases.as<ge_ext>(), I.tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
             BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
                        I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());

@@ -382,17 +382,57 @@ __global__ void __launch_bounds__(256) k_ipa_fold_scalars(scm *__restrict__ a, s
 #define TT_WINDOWS 64
 #define TT_MULTS 8
 
-// bases[p * 64 + w] = 2^(4w) * P_p for the 2*M0 + 1 base points G[0..M0), H[0..M0), B  (the only 252-doubling chain of the tail)
+// bases[p * 64 + w] = 2^(4w) * P_p for the 2*M0 + 1 base points G[0..M0), H[0..M0), B  (the only 252-doubling chain of the tail).
+// One dependent chain per point, so the chain is shortened the way k_msm_horner does it: a block of four waves owns 64 points
+// and wave k computes the k-th of the four independent field products of every doubling step (first the four squarings, then
+// the four products); the operands travel through LDS in a word-major layout [coordinate][limb][lane] (no bank conflicts).
+struct CoopLds { uint32_t c[4][8][64]; uint32_t s[4][8][64]; };
+__device__ __forceinline__ fe coop_ld(const uint32_t (&a)[8][64], uint32_t lane) { fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = a[j][lane];
+    return r; }
+__device__ __forceinline__ void coop_st(uint32_t (&a)[8][64], uint32_t lane, const fe &x) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) a[j][lane] = x.v[j]; }
+__device__ __forceinline__ void coop_dbl(CoopLds &L, uint32_t wv, uint32_t lane) {
+    // L.c = (X, Y, Z, T) of this lane's point -> doubled point in L.c
+    const fe in = (wv == 3) ? fe_add(coop_ld(L.c[0], lane), coop_ld(L.c[1], lane)) : coop_ld(L.c[wv], lane);          // X, Y, Z, X+Y
+    const fe sq = fe_sq(in);
+    __syncthreads();
+    coop_st(L.s[wv], lane, sq);                                     // XX, YY, ZZ, (X+Y)^2
+    __syncthreads();
+    const fe XX = coop_ld(L.s[0], lane), YY = coop_ld(L.s[1], lane);
+    const fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    fe a, b;
+    if (wv == 1) { a = YpX; b = YmX; }                              // Y3 = YpX * YmX
+    else {
+        const fe ZZ = coop_ld(L.s[2], lane);
+        const fe cT = fe_sub(fe_add(ZZ, ZZ), YmX), cX = fe_sub(coop_ld(L.s[3], lane), YpX);
+        if (wv == 0) { a = cX; b = cT; }                            // X3 = cX * cT
+        else if (wv == 2) { a = YmX; b = cT; }                      // Z3 = YmX * cT
+        else { a = cX; b = YpX; }                                   // T3 = cX * YpX
+    }
+    coop_st(L.c[wv], lane, fe_mul(a, b));
+    __syncthreads();
+}
 __global__ void __launch_bounds__(256) k_tt_bases(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, const ge_niels *__restrict__ B,
                                                   ge_ext *__restrict__ bases, uint32_t M0) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= 2 * M0 + 1) return;
-    const ge_niels q = p < M0 ? G[p] : (p < 2 * M0 ? H[p - M0] : B[0]);
-    ge_ext cur = ge_madd(ge_identity(), q);
-    ge_ext *dst = bases + (size_t)p * TT_WINDOWS;
+    __shared__ CoopLds L;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t count = 2 * M0 + 1;
+    const uint32_t p = blockIdx.x * 64 + lane;
+    const bool live = p < count;
+    const uint32_t q_idx = live ? p : count - 1;                    // idle lanes shadow the last point: whole block stays in step
+    if (wv == 0) {
+        const ge_niels q = q_idx < M0 ? G[q_idx] : (q_idx < 2 * M0 ? H[q_idx - M0] : B[0]);
+        const ge_ext e = ge_madd(ge_identity(), q);
+        coop_st(L.c[0], lane, e.X); coop_st(L.c[1], lane, e.Y); coop_st(L.c[2], lane, e.Z); coop_st(L.c[3], lane, e.T);
+    }
+    __syncthreads();
+    fe *dst = reinterpret_cast<fe *>(bases + (size_t)q_idx * TT_WINDOWS) + wv;       // wave k stores coordinate k (ge_ext = X, Y, Z, T)
     for (uint32_t w = 0; w < TT_WINDOWS; w++) {
-        dst[w] = cur;
-        if (w + 1 < TT_WINDOWS) { cur = ge_dbl(cur); cur = ge_dbl(cur); cur = ge_dbl(cur); cur = ge_dbl(cur); }
+        if (live) dst[4 * w] = coop_ld(L.c[wv], lane);
+        if (w + 1 < TT_WINDOWS) { coop_dbl(L, wv, lane); coop_dbl(L, wv, lane); coop_dbl(L, wv, lane); coop_dbl(L, wv, lane); }
     }
 }
 // table[i * 8 + k] = (k + 1) * bases[i], i = p * 64 + w
