@@ -91,7 +91,7 @@ struct DeviceCircuit {
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -135,6 +135,20 @@ struct Engine::Impl {
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
+    // tt_table holds the tables of the ORIGINAL generators G[0..M0), H[0..M0) when tt_orig_M0 != 0: they survive across proofs (a circuit
+    // with N <= 2^tt_lg freezes its generators at round 0) and also serve A_I, A_O, S (k_tt_commit3)
+    uint32_t tt_orig_M0 = 0; const void *tt_orig_gens = nullptr;
+    void tt_build(const ge_niels *G, const ge_niels *H, const ge_niels *B, uint32_t M0, bool original) {
+        const uint32_t npts = 2 * M0 + 1;
+        if (original && tt_orig_M0 == M0 && tt_orig_gens == gens.p) return;
+        tt_orig_M0 = 0;
+        tt_bases.ensure((size_t)npts * TT_WINDOWS * sizeof(ge_ext));
+        tt_table.ensure((size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
+        tt_partial.ensure((size_t)3 * cdiv((uint64_t)M0 * 16, 256) * sizeof(ge_ext));
+        BPG_LAUNCH((*this), k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), G, H, B, tt_bases.as<ge_ext>(), M0);
+        BPG_LAUNCH((*this), k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), tt_bases.as<ge_ext>(), tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
+        if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
+    }
     PinBuf h_naf;
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
@@ -541,7 +555,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
 
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
     const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind
-    const bool merged = expanded || n < 4096;         // nothing worth hiding: one MSM pass for A_I, A_O, S after the draws (one serial tail, not three)
+    const bool tabled = I.tt_lg > 0 && N <= (1ull << I.tt_lg) && n > 0;   // the generators have (or get) window tables: A_I, A_O, S are table sums
+    if (tabled) I.tt_build(Gtab, Htab, Bn, (uint32_t)N, true);
+    const bool merged = expanded || tabled || n < 4096;   // nothing worth hiding: A_I, A_O, S in one pass after the draws (one serial tail, not three)
     if (!merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
@@ -596,7 +612,13 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
-    if (merged) {
+    if (tabled) {
+        const uint32_t M0 = (uint32_t)N, nblk = cdiv((uint64_t)M0 * 16, 256);
+        BPG_LAUNCH(I, k_tt_commit3, dim3(nblk, 3), dim3(256), I.tt_table.as<ge_pniels>(), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR,
+                   (uint32_t)n, M0, I.tt_partial.as<ge_ext>());
+        BPG_LAUNCH(I, k_tt_commit3_finish, dim3(3), dim3(256), I.tt_partial.as<ge_ext>(), nblk, I.extras.as<scm>(),
+                   I.ped_table.as<ge_pniels>() + (size_t)TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
+    } else if (merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
         seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
@@ -709,13 +731,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         if (!tt_on && I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) {
             // freeze the generators at this level: window tables for G[0..M0), H[0..M0) and B
             tt_on = true; tt_lgM0 = ceil_log2(mcur); tt_j = 0; tt_cur = 0;
-            const uint32_t M0 = (uint32_t)mcur, npts = 2 * M0 + 1;
-            I.tt_bases.ensure((size_t)npts * TT_WINDOWS * sizeof(ge_ext));
-            I.tt_table.ensure((size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
+            const uint32_t M0 = (uint32_t)mcur;
             I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
-            I.tt_partial.ensure((size_t)2 * cdiv((uint64_t)M0 * 8, 256) * sizeof(ge_ext));
-            BPG_LAUNCH(I, k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), Gst, Hst, Bn, I.tt_bases.as<ge_ext>(), M0);
-            BPG_LAUNCH(I, k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), I.tt_bases.as<ge_ext>(), I.tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
+            I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_lg)
             BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
                        I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
         }

@@ -519,6 +519,60 @@ __global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ 
     }
     if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
 }
+// A_I, A_O, S of a circuit whose generators already have window tables (N <= 2^14: the tables of the frozen IPA tail are those of
+// the original generators and live with the context): blockIdx.y = 0: <a_L,G> + <a_R,H>, 1: <a_O,G>, 2: <s_L,G> + <s_R,H>; same thread
+// layout as k_tt_round (8 threads per base point, 8 windows each), block partials to partial[3][gridDim.x].
+__global__ void __launch_bounds__(256) k_tt_commit3(const ge_pniels *__restrict__ table, const scm *__restrict__ aL, const scm *__restrict__ aR,
+                                                    const scm *__restrict__ aO, const scm *__restrict__ sL, const scm *__restrict__ sR,
+                                                    uint32_t n, uint32_t M0, ge_ext *__restrict__ partial) {
+    __shared__ ge_ext lds[256];
+    const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = tid >> 3, g = tid & 7u;
+    ge_ext acc = ge_identity();
+    const bool isH = e >= M0;
+    const uint32_t p = isH ? e - M0 : e;
+    if (e < 2 * M0 && p < n && !(cls == 1 && isH)) {
+        const scm s = cls == 0 ? (isH ? aR[p] : aL[p]) : (cls == 1 ? aO[p] : (isH ? sR[p] : sL[p]));
+        uint32_t w[8]; tt_biased_words(w, s);
+        const ge_pniels *tbl = table + ((size_t)(isH ? M0 : 0u) + p) * (TT_WINDOWS * TT_MULTS) + (size_t)g * 8 * TT_MULTS;
+        const uint32_t word = w[g];
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; k++) {
+            const int32_t d = (int32_t)((word >> (4 * k)) & 15u) - 8;
+            if (d == 0) continue;
+            const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
+        }
+    }
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+}
+// block k: out[k] = sum of partial[k][0..nblk) + blind[k] * (fixed base whose window table is tableX)
+__global__ void __launch_bounds__(256) k_tt_commit3_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ blind,
+                                                           const ge_pniels *__restrict__ tableX, ge_ext *__restrict__ out) {
+    __shared__ ge_ext lds[256];
+    const uint32_t cls = blockIdx.x;
+    ge_ext acc = ge_identity();
+    for (uint32_t s = threadIdx.x; s < nblk; s += 256) acc = ge_add(acc, partial[cls * nblk + s]);
+    if (threadIdx.x < TT_WINDOWS) {
+        uint32_t w[8]; tt_biased_words(w, blind[cls]);
+        const int32_t d = (int32_t)((w[threadIdx.x >> 3] >> (4 * (threadIdx.x & 7u))) & 15u) - 8;
+        if (d != 0) {
+            const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            acc = ge_add_pniels_signed(acc, tableX[threadIdx.x * TT_MULTS + mag - 1], neg);
+        }
+    }
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[cls] = lds[0];
+}
 // block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>, compress
 __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ a, const scm *__restrict__ b,
                                                    uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, uint8_t *__restrict__ out) {
