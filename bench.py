@@ -244,7 +244,7 @@ def main():
         out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle", "value": q_total * args.steps / elapsed,
                "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u32 limbs (255-bit modular integer arithmetic)", "data": "synthetic",
+               "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
                "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
                                       % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                           "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)"},
