@@ -31,10 +31,13 @@ void chk(bpg_status s, const char *what) {
 }
 
 // ---------------------------------------------------------------------------------------------- small helpers
-Bytes from_hex(const std::string &h) {
-    std::string s = h.size() % 2 ? "0" + h : h;
+Bytes from_hex(const std::string &s) {                   // hex::decode of the reference: even length, hex digits only, else it panics
+    if (s.size() % 2) fail("odd number of hex digits");
     Bytes out(s.size() / 2);
-    for (size_t i = 0; i < out.size(); i++) out[i] = (uint8_t)std::stoul(s.substr(2 * i, 2), nullptr, 16);
+    for (size_t i = 0; i < out.size(); i++) {
+        if (!isxdigit((unsigned char)s[2 * i]) || !isxdigit((unsigned char)s[2 * i + 1])) fail("invalid hex digit");
+        out[i] = (uint8_t)std::stoul(s.substr(2 * i, 2), nullptr, 16);
+    }
     return out;
 }
 std::string to_hex(const uint8_t *p, size_t n) {
