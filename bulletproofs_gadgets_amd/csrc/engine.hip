@@ -158,6 +158,8 @@ struct Engine::Impl {
     uint64_t gens_cap = 0;
 
     void msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result);
+    void inner_product(Transcript &T, std::vector<uint8_t> &proof, uint64_t n, uint64_t N, const Scalar &yinv, const Scalar &u_ch, const Scalar &w,
+                       const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0);
 };
 
 Engine::Engine(int device) : device_(device) {
@@ -518,6 +520,188 @@ void Engine::free_circuit(DeviceCircuit *c) {
     delete c;
 }
 
+// ------------------------------------------------------------------------------------------------ inner-product argument
+// InnerProductProof::create (dalek inner_product_proof.rs) on l(x) = lv, r(x) = rv with G_factors = (1.., u..), H_factors = y^-i * G_factors
+// and Q = w * B: appends L_k, R_k (lg N pairs) and the final a, b to `proof`.  Rounds above 2^tt_lg generators: grouped folds with
+// bucket-method MSMs; from there on: frozen generators and window tables (kernels.cuh).
+void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uint64_t n, uint64_t N, const Scalar &yinv, const Scalar &u_ch,
+                                 const Scalar &w, const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0) {
+    Impl &I = *this;
+    const uint32_t lgN = ceil_log2(N);
+    auto lap = [&](double *slot) { if (tm) { HIPCHK(hipStreamSynchronize(st)); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
+    T.innerproduct_domain_sep(N);
+    std::vector<Scalar> yinv_pow2(lgN + 1);
+    yinv_pow2[0] = yinv; for (uint32_t k = 1; k <= lgN; k++) yinv_pow2[k] = yinv_pow2[k - 1] * yinv_pow2[k - 1];
+    scm *a = I.lv.as<scm>(), *b = I.rv.as<scm>();
+    if (lgN) {
+        const uint64_t half = N / 2;
+        I.ipa_s.ensure(4 * half * sizeof(scm));
+        I.ipa_tabA.ensure(2 * half * sizeof(ge_niels)); I.ipa_tabB.ensure((half > 1 ? half : 2) * sizeof(ge_niels));
+        I.scratch_ext.ensure(2 * half * sizeof(ge_ext));
+        I.naf.ensure(4096);
+    }
+    Scalar Gamma = Scalar::one(), Eta = Scalar::one();
+    const ge_niels *Gst = Gtab, *Hst = Htab;
+    const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
+    uint64_t mcur = N;
+    // table-driven tail state (kernels.cuh "table-driven IPA tail")
+    bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv;
+    // grouped-fold state
+    const uint32_t GRP_STRIDE = 64;
+    uint32_t g_j = 0, g_r = 1, g_cur = 0, g_index = 0; uint64_t g_M = N; bool g_first = true; std::vector<Scalar> g_us;
+    for (uint32_t round = 0; round < lgN; round++) {
+        const uint64_t h = mcur / 2;
+        const bool first = round == 0;
+        if (!tt_on && I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) {
+            // freeze the generators at this level: window tables for G[0..M0), H[0..M0) and B
+            tt_on = true; tt_lgM0 = ceil_log2(mcur); tt_j = 0; tt_cur = 0;
+            const uint32_t M0 = (uint32_t)mcur;
+            I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
+            I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_lg)
+            BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
+                       I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
+        }
+        if (tt_on) {
+            const uint32_t M0 = 1u << tt_lgM0;
+            scm *c0 = I.tt_c.as<scm>() + (size_t)tt_cur * 2 * M0, *c1 = I.tt_c.as<scm>() + (size_t)(tt_cur ^ 1u) * 2 * M0;
+            if (tt_j > 0) {     // apply the previous round's challenge: fold a, b (2*mcur -> mcur) and double the coefficient tables
+                BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(mcur, 1ull << (tt_j - 1)), 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)mcur,
+                           c0, c1, 1u << (tt_j - 1), M0);
+                tt_cur ^= 1u; std::swap(c0, c1);
+            }
+            const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
+            BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
+                       I.tt_partial.as<ge_ext>());
+            BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
+                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.comp.as<uint8_t>());
+            HIPCHK(hipGetLastError());
+            uint8_t lr[64];
+            HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            lap(tm ? &tm->ipa_msm : nullptr);
+            T.append_point("L", lr); T.append_point("R", lr + 32);
+            proof.insert(proof.end(), lr, lr + 64);
+            tt_u = T.challenge_scalar("u"); tt_uinv = tt_u.invert();
+            tt_j++;
+            mcur = h;
+            if (round + 1 == lgN) {   // last round: only the scalar fold remains
+                BPG_LAUNCH(I, k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)h);
+                HIPCHK(hipGetLastError());
+            }
+            continue;
+        }
+        // ---- grouped fold rounds (kernels.cuh k_ipa_prep / k_fold_points): sub-round g_j of a group of g_r rounds on tables of size g_M
+        if (g_j == 0) {
+            g_M = mcur; g_first = first;
+            uint32_t left = ceil_log2(mcur);                               // rounds until the tables would be a single point
+            if (I.tt_lg > 0 && left > I.tt_lg) left -= I.tt_lg;            // ... or until the tail freezes them
+            g_r = std::min<uint32_t>(I.fold_group, left);
+            g_us.clear();
+            I.grp_c.ensure(4 * GRP_STRIDE * sizeof(scm));
+            g_cur = 0;
+            hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, st, I.grp_c.as<scm>(), (uint32_t)GRP_STRIDE, to_scm(Gamma), to_scm(Eta));
+        }
+        scm *c0 = I.grp_c.as<scm>() + (size_t)g_cur * 2 * GRP_STRIDE;
+        const uint64_t cnt = g_M / 2;                                       // expanded scalars per side: h * 2^g_j
+        scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + cnt, *sRG = sLH + cnt, *sRH = sRG + cnt;
+        const uint32_t blocks = std::min<uint32_t>(cdiv(cnt, 256), 1024);
+        const uint32_t lgh = ceil_log2(h);
+        I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
+        BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), c0, c0 + GRP_STRIDE, uch_m,
+                           (uint32_t)g_first, (uint32_t)n, lgh, g_j, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
+        BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
+        BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
+        {
+            MsmSegs S = seg_new();
+            const uint32_t lgblk = g_j ? lgh : 31u;                         // every other block of h points of the group-start tables
+            seg_push(S, sLG, Gst + h, (uint32_t)cnt, 0, lgblk);
+            seg_push(S, sLH, Hst, (uint32_t)cnt, 0, lgblk);
+            seg_push(S, I.extras.as<scm>() + 3, Bn, 1, 0);
+            seg_push(S, sRG, Gst, (uint32_t)cnt, 1, lgblk);
+            seg_push(S, sRH, Hst + h, (uint32_t)cnt, 1, lgblk);
+            seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
+            I.msm(S, 2, I.msm_result.as<ge_ext>());
+        }
+        BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
+        HIPCHK(hipGetLastError());
+        uint8_t lr[64];
+        HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        lap(tm ? &tm->ipa_msm : nullptr);
+        T.append_point("L", lr); T.append_point("R", lr + 32);
+        proof.insert(proof.end(), lr, lr + 64);
+        const Scalar u = T.challenge_scalar("u"), uinv = u.invert();
+        g_us.push_back(u);
+        {   // fold a, b and extend the coefficient tables cG, cH (2^g_j -> 2^(g_j+1) entries)
+            scm *c1 = I.grp_c.as<scm>() + (size_t)(g_cur ^ 1u) * 2 * GRP_STRIDE;
+            BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(h, 1ull << g_j), 256)), dim3(256), a, b, to_scm(u), to_scm(uinv), (uint32_t)h,
+                       c0, c1, 1u << g_j, (uint32_t)GRP_STRIDE);
+            g_cur ^= 1u;
+        }
+        g_j++;
+        if (g_j == g_r) {
+            // generator fold of the whole group: Gst'[i] = Gst[i] + sum_{t>=1} sG_t Gst[i + t*Mr], same for H, with
+            // sG_t = prod_k (u_k^2)^bit_k(t), sH_t = prod_k (u_k^-2 y^-(g_M/2^k))^bit_k(t), bit_k(t) = bit (g_r - k) of t
+            const uint32_t Mr = (uint32_t)(g_M >> g_r), nterms = (1u << g_r) - 1u;
+            std::vector<Scalar> fG(g_r), fH(g_r);
+            for (uint32_t k = 1; k <= g_r; k++) {
+                const Scalar &uk = g_us[k - 1]; const Scalar ukinv = uk.invert();
+                fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
+            }
+            I.h_naf.ensure((size_t)4 * nterms * 16 * 4); I.naf.ensure((size_t)4 * nterms * 16 * 4);
+            uint32_t *hn = I.h_naf.as<uint32_t>();
+            std::memset(hn, 0, (size_t)4 * nterms * 16 * 4);
+            int32_t top = -1; double adds_fm = 0;
+            for (uint32_t q = 0; q < nterms; q++) {
+                const uint32_t t = q + 1;
+                Scalar sg = Scalar::one(), sh = Scalar::one();
+                for (uint32_t k = 1; k <= g_r; k++) if ((t >> (g_r - k)) & 1u) { sg = sg * fG[k - 1]; sh = sh * fH[k - 1]; }
+                const Scalar cls_s[4] = {sg, sg * u_ch, sh, sh * u_ch};
+                // lanes of term t that are padding generators (first group): i + t*Mr >= n
+                const uint64_t lo = (uint64_t)t * Mr, nB = !g_first ? 0 : (lo >= n ? Mr : (lo + Mr > n ? lo + Mr - n : 0));
+                for (int cls = 0; cls < 4; cls++) {
+                    if ((cls & 1) && !g_first) continue;
+                    int8_t dg[256]; const int32_t tp = naf256(cls_s[cls], dg);
+                    if (tp > top) top = tp;
+                    uint32_t *d = hn + ((size_t)cls * nterms + q) * 16; int adds = 0;
+                    for (int k = 0; k < 256; k++) { if (dg[k]) { d[k >> 5] |= 1u << (k & 31); adds++; } if (dg[k] < 0) d[8 + (k >> 5)] |= 1u << (k & 31); }
+                    adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
+                }
+            }
+            HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
+            FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
+            ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
+                const dim3 grid(cdiv(2 * Mr, 256)), block(256);
+                ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
+                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory)
+                    BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 3 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 7 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
+                else if (nterms == 15 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);
+                else BPG_LAUNCH(I, k_fold_points, grid, block, Gst, Hst, fo, nf, fg);
+            }
+            // bookkeeping for the roofline: 2*g_M points read + 2*Mr written at 32 B (information content) resp. 96/128 B (device formats);
+            // field multiplications: 8 per doubling, 7 per mixed addition
+            I.prof_note(KID_k_fold_points, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);
+            BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group
+            Gst = dst; Hst = dst + Mr;
+            for (const Scalar &uk : g_us) { Gamma = uk.invert() * Gamma; Eta = uk * Eta; }
+            g_j = 0; g_index++;
+        }
+        mcur = h;
+        lap(tm ? &tm->ipa_fold : nullptr);
+    }
+    scm ab[2];
+    HIPCHK(hipMemcpyAsync(&ab[0], a, sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&ab[1], b, sizeof(scm), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    { uint8_t o[64]; from_scm(ab[0]).to_bytes(o); from_scm(ab[1]).to_bytes(o + 32); proof.insert(proof.end(), o, o + 64); }
+}
+
 // ------------------------------------------------------------------------------------------------ prove
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
                                    const uint8_t rng_seed[32], uint32_t flags, ProveTimings *tm) {
@@ -705,177 +889,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     lap(tm ? &tm->poly : nullptr);
 
     // ---- inner-product argument
-    T.innerproduct_domain_sep(N);
-    std::vector<Scalar> yinv_pow2(lgN + 1);
-    yinv_pow2[0] = yinv; for (uint32_t k = 1; k <= lgN; k++) yinv_pow2[k] = yinv_pow2[k - 1] * yinv_pow2[k - 1];
-    scm *a = I.lv.as<scm>(), *b = I.rv.as<scm>();
-    if (lgN) {
-        const uint64_t half = N / 2;
-        I.ipa_s.ensure(4 * half * sizeof(scm));
-        I.ipa_tabA.ensure(2 * half * sizeof(ge_niels)); I.ipa_tabB.ensure((half > 1 ? half : 2) * sizeof(ge_niels));
-        I.scratch_ext.ensure(2 * half * sizeof(ge_ext));
-        I.naf.ensure(4096);
-    }
-    Scalar Gamma = Scalar::one(), Eta = Scalar::one();
-    const ge_niels *Gst = Gtab, *Hst = Htab;
-    const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
-    uint64_t mcur = N;
-    // table-driven tail state (kernels.cuh "table-driven IPA tail")
-    bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv;
-    // grouped-fold state
-    const uint32_t GRP_STRIDE = 64;
-    uint32_t g_j = 0, g_r = 1, g_cur = 0, g_index = 0; uint64_t g_M = N; bool g_first = true; std::vector<Scalar> g_us;
-    for (uint32_t round = 0; round < lgN; round++) {
-        const uint64_t h = mcur / 2;
-        const bool first = round == 0;
-        if (!tt_on && I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) {
-            // freeze the generators at this level: window tables for G[0..M0), H[0..M0) and B
-            tt_on = true; tt_lgM0 = ceil_log2(mcur); tt_j = 0; tt_cur = 0;
-            const uint32_t M0 = (uint32_t)mcur;
-            I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
-            I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_lg)
-            BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
-                       I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
-        }
-        if (tt_on) {
-            const uint32_t M0 = 1u << tt_lgM0;
-            scm *c0 = I.tt_c.as<scm>() + (size_t)tt_cur * 2 * M0, *c1 = I.tt_c.as<scm>() + (size_t)(tt_cur ^ 1u) * 2 * M0;
-            if (tt_j > 0) {     // apply the previous round's challenge: fold a, b (2*mcur -> mcur) and double the coefficient tables
-                BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(mcur, 1ull << (tt_j - 1)), 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)mcur,
-                           c0, c1, 1u << (tt_j - 1), M0);
-                tt_cur ^= 1u; std::swap(c0, c1);
-            }
-            const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
-            BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
-                       I.tt_partial.as<ge_ext>());
-            BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
-                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.comp.as<uint8_t>());
-            HIPCHK(hipGetLastError());
-            uint8_t lr[64];
-            HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            lap(tm ? &tm->ipa_msm : nullptr);
-            T.append_point("L", lr); T.append_point("R", lr + 32);
-            proof.insert(proof.end(), lr, lr + 64);
-            tt_u = T.challenge_scalar("u"); tt_uinv = tt_u.invert();
-            tt_j++;
-            mcur = h;
-            if (round + 1 == lgN) {   // last round: only the scalar fold remains
-                BPG_LAUNCH(I, k_ipa_fold_scalars, dim3(cdiv(h, 256)), dim3(256), a, b, to_scm(tt_u), to_scm(tt_uinv), (uint32_t)h);
-                HIPCHK(hipGetLastError());
-            }
-            continue;
-        }
-        // ---- grouped fold rounds (kernels.cuh k_ipa_prep / k_fold_points): sub-round g_j of a group of g_r rounds on tables of size g_M
-        if (g_j == 0) {
-            g_M = mcur; g_first = first;
-            uint32_t left = ceil_log2(mcur);                               // rounds until the tables would be a single point
-            if (I.tt_lg > 0 && left > I.tt_lg) left -= I.tt_lg;            // ... or until the tail freezes them
-            g_r = std::min<uint32_t>(I.fold_group, left);
-            g_us.clear();
-            I.grp_c.ensure(4 * GRP_STRIDE * sizeof(scm));
-            g_cur = 0;
-            hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, st, I.grp_c.as<scm>(), (uint32_t)GRP_STRIDE, to_scm(Gamma), to_scm(Eta));
-        }
-        scm *c0 = I.grp_c.as<scm>() + (size_t)g_cur * 2 * GRP_STRIDE;
-        const uint64_t cnt = g_M / 2;                                       // expanded scalars per side: h * 2^g_j
-        scm *sLG = I.ipa_s.as<scm>(), *sLH = sLG + cnt, *sRG = sLH + cnt, *sRH = sRG + cnt;
-        const uint32_t blocks = std::min<uint32_t>(cdiv(cnt, 256), 1024);
-        const uint32_t lgh = ceil_log2(h);
-        I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
-        BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), c0, c0 + GRP_STRIDE, uch_m,
-                           (uint32_t)g_first, (uint32_t)n, lgh, g_j, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
-        BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
-        BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
-        {
-            MsmSegs S = seg_new();
-            const uint32_t lgblk = g_j ? lgh : 31u;                         // every other block of h points of the group-start tables
-            seg_push(S, sLG, Gst + h, (uint32_t)cnt, 0, lgblk);
-            seg_push(S, sLH, Hst, (uint32_t)cnt, 0, lgblk);
-            seg_push(S, I.extras.as<scm>() + 3, Bn, 1, 0);
-            seg_push(S, sRG, Gst, (uint32_t)cnt, 1, lgblk);
-            seg_push(S, sRH, Hst + h, (uint32_t)cnt, 1, lgblk);
-            seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
-            I.msm(S, 2, I.msm_result.as<ge_ext>());
-        }
-        BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
-        HIPCHK(hipGetLastError());
-        uint8_t lr[64];
-        HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        lap(tm ? &tm->ipa_msm : nullptr);
-        T.append_point("L", lr); T.append_point("R", lr + 32);
-        proof.insert(proof.end(), lr, lr + 64);
-        const Scalar u = T.challenge_scalar("u"), uinv = u.invert();
-        g_us.push_back(u);
-        {   // fold a, b and extend the coefficient tables cG, cH (2^g_j -> 2^(g_j+1) entries)
-            scm *c1 = I.grp_c.as<scm>() + (size_t)(g_cur ^ 1u) * 2 * GRP_STRIDE;
-            BPG_LAUNCH(I, k_tt_advance, dim3(cdiv(std::max<uint64_t>(h, 1ull << g_j), 256)), dim3(256), a, b, to_scm(u), to_scm(uinv), (uint32_t)h,
-                       c0, c1, 1u << g_j, (uint32_t)GRP_STRIDE);
-            g_cur ^= 1u;
-        }
-        g_j++;
-        if (g_j == g_r) {
-            // generator fold of the whole group: Gst'[i] = Gst[i] + sum_{t>=1} sG_t Gst[i + t*Mr], same for H, with
-            // sG_t = prod_k (u_k^2)^bit_k(t), sH_t = prod_k (u_k^-2 y^-(g_M/2^k))^bit_k(t), bit_k(t) = bit (g_r - k) of t
-            const uint32_t Mr = (uint32_t)(g_M >> g_r), nterms = (1u << g_r) - 1u;
-            std::vector<Scalar> fG(g_r), fH(g_r);
-            for (uint32_t k = 1; k <= g_r; k++) {
-                const Scalar &uk = g_us[k - 1]; const Scalar ukinv = uk.invert();
-                fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
-            }
-            I.h_naf.ensure((size_t)4 * nterms * 16 * 4); I.naf.ensure((size_t)4 * nterms * 16 * 4);
-            uint32_t *hn = I.h_naf.as<uint32_t>();
-            std::memset(hn, 0, (size_t)4 * nterms * 16 * 4);
-            int32_t top = -1; double adds_fm = 0;
-            for (uint32_t q = 0; q < nterms; q++) {
-                const uint32_t t = q + 1;
-                Scalar sg = Scalar::one(), sh = Scalar::one();
-                for (uint32_t k = 1; k <= g_r; k++) if ((t >> (g_r - k)) & 1u) { sg = sg * fG[k - 1]; sh = sh * fH[k - 1]; }
-                const Scalar cls_s[4] = {sg, sg * u_ch, sh, sh * u_ch};
-                // lanes of term t that are padding generators (first group): i + t*Mr >= n
-                const uint64_t lo = (uint64_t)t * Mr, nB = !g_first ? 0 : (lo >= n ? Mr : (lo + Mr > n ? lo + Mr - n : 0));
-                for (int cls = 0; cls < 4; cls++) {
-                    if ((cls & 1) && !g_first) continue;
-                    int8_t dg[256]; const int32_t tp = naf256(cls_s[cls], dg);
-                    if (tp > top) top = tp;
-                    uint32_t *d = hn + ((size_t)cls * nterms + q) * 16; int adds = 0;
-                    for (int k = 0; k < 256; k++) { if (dg[k]) { d[k >> 5] |= 1u << (k & 31); adds++; } if (dg[k] < 0) d[8 + (k >> 5)] |= 1u << (k & 31); }
-                    adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
-                }
-            }
-            HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
-            FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
-            ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
-                const dim3 grid(cdiv(2 * Mr, 256)), block(256);
-                ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
-                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory)
-                    BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 3 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 7 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 15 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);
-                else BPG_LAUNCH(I, k_fold_points, grid, block, Gst, Hst, fo, nf, fg);
-            }
-            // bookkeeping for the roofline: 2*g_M points read + 2*Mr written at 32 B (information content) resp. 96/128 B (device formats);
-            // field multiplications: 8 per doubling, 7 per mixed addition
-            I.prof_note(KID_k_fold_points, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);
-            BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group
-            Gst = dst; Hst = dst + Mr;
-            for (const Scalar &uk : g_us) { Gamma = uk.invert() * Gamma; Eta = uk * Eta; }
-            g_j = 0; g_index++;
-        }
-        mcur = h;
-        lap(tm ? &tm->ipa_fold : nullptr);
-    }
-    scm ab[2];
-    HIPCHK(hipMemcpyAsync(&ab[0], a, sizeof(scm), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&ab[1], b, sizeof(scm), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    { uint8_t o[64]; from_scm(ab[0]).to_bytes(o); from_scm(ab[1]).to_bytes(o + 32); proof.insert(proof.end(), o, o + 64); }
+    I.inner_product(T, proof, n, N, yinv, u_ch, w, Gtab, Htab, Bn, tm, t0);
     if (tm) { tm->ipa = tm->ipa_msm + tm->ipa_fold; tm->total += now_ms() - t_begin; }
     return proof;
 }
