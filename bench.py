@@ -241,7 +241,7 @@ def main():
                     "valu": {"unit": "field-mult/s", "achieved": fold["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
                              "frac": (fold["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
                              "peak_source": "k_bench_fe_mul microbenchmark on this device"}}
-        out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle", "value": q_total * args.steps / elapsed,
+        out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU", "value": q_total * args.steps / elapsed,
                "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
