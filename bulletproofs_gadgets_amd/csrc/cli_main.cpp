@@ -9,6 +9,8 @@
 // Blinding factors: 64 bytes of /dev/urandom reduced mod l per factor (the reference uses thread_rng()); with BPG_CLI_SEED set they
 // come from SHAKE256(seed || counter) so that two runs - and the Python driver bulletproofs_gadgets_amd/cli.py - produce the same
 // files.  BPG_CLI_RNG_SEED (64 hex digits) fixes the 32 bytes that replace upstream's thread_rng() inside prove().
+#include <cctype>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -317,7 +319,12 @@ struct ProverRun {
     }
 
     int run() {
+        const bool timing = std::getenv("BPG_CLI_TIMING") != nullptr;         // phase times on stderr
+        auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t0 = now();
+        auto lap = [&](const char *what) { if (timing) { double t1 = now(); std::fprintf(stderr, "  %-28s %8.2f ms\n", what, t1 - t0); t0 = t1; } };
         chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
+        lap("context (HIP init, bases)");
         chk(bpg_transcript_new(reinterpret_cast<const uint8_t *>(name.data()), name.size(), &tr), "Transcript::new");
         chk(bpg_prover_new(ctx, tr, &p), "Prover::new");
         for (auto &kv : read_vars(name + ".inst")) instance[kv.first] = kv.second;
@@ -329,17 +336,21 @@ struct ProverRun {
             for (size_t j = 0; j < k; j++) { w.coms.emplace_back(coms.begin() + 32 * j, coms.begin() + 32 * j + 32); coms_lines.push_back("C" + kv.first.substr(1) + "-" + std::to_string(j) + " = 0x" + to_hex(&coms[32 * j], 32) + "\n"); }
             witness[kv.first] = w;
         }
+        lap("witness commitments");
         lines = read_lines(name + ".gadgets");
         Cs top; top.p = p;
         run_block(0, top, 0);
+        lap("gadget assembly");
         std::printf("%llu\n", (unsigned long long)bpg_prover_num_constraints(p));          // prover.rs:89
         const uint64_t n = bpg_prover_num_multiplications(p), cap = round_pow2(n);
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
+        lap("generators");
         Bytes rng_seed(32);
         if (const char *e = std::getenv("BPG_CLI_RNG_SEED")) { rng_seed = from_hex(e); rng_seed.resize(32); }
         else { std::ifstream r("/dev/urandom", std::ios::binary); if (!r.read(reinterpret_cast<char *>(rng_seed.data()), 32)) fail("cannot read /dev/urandom"); }
         uint64_t plen = bpg_proof_size(n, 0); Bytes proof(plen);
         chk(bpg_prover_prove(p, cap, rng_seed.data(), 0, proof.data(), &plen, nullptr), "Prover::prove");
+        lap("prove (upload + proof)");
         { std::ofstream f(name + ".coms"); for (const std::string &l : coms_lines) f << l; }
         { std::ofstream f(name + ".proof", std::ios::binary); f.write(reinterpret_cast<const char *>(proof.data()), (std::streamsize)plen); }
         return 0;
