@@ -73,3 +73,104 @@ def test_native_prover_reports_malformed_input(tmp_path):
     (tmp_path / "bad.wtns").write_text("W0 = 0x01\n")
     r = subprocess.run([str(prover_bin), "bad"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 101 and "unknown gadget line" in r.stderr      # the reference unwrap()s: panic, exit code 101
+
+
+def _random_gadget_files(stem, seed):
+    """A seeded random .gadgets/.inst/.wtns triple whose statements hold: every gadget kind, and OR blocks (also nested) that mix
+    false clauses with a true one."""
+    import random
+    from bulletproofs_gadgets_amd import workloads
+    rnd = random.Random(seed)
+    inst, wtns, lines = [], [], []
+
+    def I(b):
+        inst.append(b); return "I%d" % (len(inst) - 1)
+
+    def W(b):
+        wtns.append(b); return "W%d" % (len(wtns) - 1)
+
+    def rb(n, first_max=0x0f):
+        return bytes([rnd.randrange(1, first_max + 1)]) + bytes(rnd.randrange(256) for _ in range(n - 1))
+
+    def true_line():
+        k = rnd.randrange(7)
+        if k == 0:
+            v = rnd.randrange(50, 200); return "BOUND %s %s %s" % (W(bytes([v])), I(bytes([rnd.randrange(0, v + 1)])), I(bytes([rnd.randrange(v, 256)])))
+        if k == 1:
+            pre = rb(rnd.choice([5, 20, 31, 40])); return "HASH %s %s" % (I(bpg.scalar_to_be(bpg.mimc_hash(pre))), W(pre))
+        if k == 2:
+            v = rb(rnd.choice([8, 32, 45])); return rnd.choice(["EQUALS %s %s" % (W(v), I(v)), "EQUALS %s %s" % (I(v), W(v)), "EQUALS %s %s" % (W(v), W(v))])
+        if k == 3:
+            v = rb(rnd.choice([8, 32])); u = bytes([v[0] ^ 1]) + v[1:]; return "UNEQUAL %s %s" % (W(v), rnd.choice([I, W])(u))
+        if k == 4:
+            a = rnd.randrange(1, 1 << 60); b = a + rnd.randrange(1, 1 << 60); return "LESS_THAN %s %s" % (W(a.to_bytes(9, "big")), W(b.to_bytes(9, "big")))
+        if k == 5:
+            m = rb(4); others = [rb(4) for _ in range(3)]
+            names = [I(others[0]), W(others[1]), I(m), W(others[2])]; rnd.shuffle(names)
+            return "SET_MEMBER %s %s" % (W(m), " ".join(names))
+        # MERKLE over ((W I) (I W)) with the root computed by an assembly-only prover
+        leaves = [rb(12) for _ in range(4)]
+        hashed = [bpg.mimc_hash(x) for x in leaves]
+        probe = bpg.Prover(None, bpg.Transcript(b"probe"))
+        bpg.MerkleTree256(bytes(32), hashed, [], "((I I) (I I))").prove(probe, [], [])
+        root = probe.instance().aO[-32:]
+        return "MERKLE %s ((%s %s) (%s %s))" % (I(root[::-1]), W(leaves[0]), I(leaves[1]), I(leaves[2]), W(leaves[3]))
+
+    def false_line():
+        v = rb(8); return "EQUALS %s %s" % (W(v), I(bytes([v[0] ^ 1]) + v[1:]))
+
+    def or_block(depth):
+        out = ["OR", "["]
+        clauses = rnd.randrange(2, 4); good = rnd.randrange(clauses)
+        for c in range(clauses):
+            out.append("{")
+            if c == good:
+                out.append(true_line() if depth or rnd.random() < 0.6 else "\n".join(or_block(depth + 1)))
+                if rnd.random() < 0.4: out.append(true_line())
+            else:
+                out.append(false_line())
+                if rnd.random() < 0.3: out.append(true_line())
+            out.append("}")
+        out.append("]")
+        return out
+
+    for _ in range(rnd.randrange(2, 5)):
+        lines += [true_line()] if rnd.random() < 0.7 else or_block(0)
+    text = "\n".join(lines) + "\n"
+    open(stem + ".gadgets", "w").write(text)
+    open(stem + ".inst", "w").write("".join("I%d = 0x%s\n" % (k, b.hex()) for k, b in enumerate(inst)))
+    open(stem + ".wtns", "w").write("".join("W%d = 0x%s\n" % (k, b.hex()) for k, b in enumerate(wtns)))
+    return text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_gadget_files_native_and_python_agree(ctx, tmp_path, seed):
+    prover_bin, verifier_bin = bpg_build.build_cli()
+    a, b = tmp_path / "native", tmp_path / "python"
+    a.mkdir(); b.mkdir()
+    text = _random_gadget_files(str(a / "rnd"), 4242 + seed)
+    for ext in ("gadgets", "inst", "wtns"):
+        shutil.copy(a / ("rnd." + ext), b / ("rnd." + ext))
+    env = dict(os.environ, BPG_CLI_SEED="fuzz", BPG_CLI_RNG_SEED="11" * 32)
+    r = subprocess.run([str(prover_bin), "rnd"], cwd=a, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (text, r.stderr)
+    cwd = os.getcwd()
+    try:
+        os.chdir(b)
+        p, proof = cli.prover("rnd", ctx=ctx, seed=b"fuzz", rng_seed=bytes([0x11]) * 32, quiet=True)
+        assert cli.verifier("rnd", ctx=ctx, quiet=True), text
+    finally:
+        os.chdir(cwd)
+    assert (a / "rnd.coms").read_text() == (b / "rnd.coms").read_text(), text
+    assert (a / "rnd.proof").read_bytes() == proof, text
+    v = subprocess.run([str(verifier_bin), "rnd"], cwd=a, capture_output=True, text=True, timeout=300)
+    assert (v.returncode, v.stdout.strip()) == (0, "true"), (text, v.stderr)
+    # make the statement false: break the first instance value -> the verifier must say false (or the prover's circuit is unsatisfied)
+    inst_lines = (a / "rnd.inst").read_text().splitlines()
+    if inst_lines:
+        name, val = inst_lines[0].split(" = 0x")
+        inst_lines[0] = "%s = 0x%s" % (name, val[:-1] + ("0" if val[-1] != "0" else "1"))
+        (a / "rnd.inst").write_text("\n".join(inst_lines) + "\n")
+        v = subprocess.run([str(verifier_bin), "rnd"], cwd=a, capture_output=True, text=True, timeout=300)
+        assert v.returncode in (0, 1, 101)               # 0 only if the changed value sits in a false OR clause or is unused
