@@ -267,6 +267,47 @@ def _verify_flat(ctx, inst, transcript_state, commitments, proof, seed=bytes(32)
     return lib().bpg_r1cs_verify(ctx._h, C.byref(cs), ts, C.c_uint64(inst.m), commitments, proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags))
 
 
+class _BatchItem(C.Structure):
+    _fields_ = [("inst", C.POINTER(R1CSInstance)), ("transcript_state", C.c_void_p), ("m", C.c_uint64), ("v_blinding", C.c_char_p),
+                ("rng_seed", C.c_char_p), ("flags", C.c_uint32), ("proof_out", C.c_void_p), ("proof_len", C.POINTER(C.c_uint64))]
+
+
+class ProverPool:
+    """bpg_pool_*: `workers` engine contexts + host threads on one GPU that prove a batch of independent instances concurrently (the
+    serial TranscriptRng chain of one proof overlaps the kernels of the others). Same bytes as proving the items one by one."""
+
+    def __init__(self, device: int = 0, workers: int = 8, gens_capacity: int = 0):
+        self._h = C.c_void_p()
+        _chk(lib().bpg_pool_create(C.c_int32(device), C.c_uint32(workers), C.c_uint64(gens_capacity), C.byref(self._h)))
+        self.workers = workers
+
+    def prove_batch(self, items):
+        """items: [(FlatInstance, transcript_state, v_blinding, rng_seed, flags)] -> [(proof bytes, transcript state after)]"""
+        n = len(items)
+        arr = (_BatchItem * max(n, 1))()
+        keep = []
+        for k, (inst, state, vb, seed, flags) in enumerate(items):
+            cs = inst.cstruct()
+            ts = _buf(203); ts.raw = bytes(state)
+            cap = lib().bpg_proof_size(inst.n, flags)
+            out = _buf(cap); ln = C.c_uint64(cap)
+            keep.append((cs, ts, out, ln, vb, seed))
+            arr[k].inst = C.pointer(cs); arr[k].transcript_state = C.cast(ts, C.c_void_p); arr[k].m = inst.m
+            arr[k].v_blinding = vb; arr[k].rng_seed = seed; arr[k].flags = flags
+            arr[k].proof_out = C.cast(out, C.c_void_p); arr[k].proof_len = C.pointer(ln)
+        status = (C.c_int32 * max(n, 1))()
+        _chk(lib().bpg_pool_prove(self._h, C.c_uint64(n), arr, status))
+        return [(k[2].raw[:k[3].value], k[1].raw[:203]) for k in keep]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bpg_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
 class ResidentCircuit:
     def __init__(self, ctx, h, n, m):
         self.ctx, self._h, self.n, self.m = ctx, h, n, m

@@ -2,7 +2,9 @@
 // HIP engine (engine.hip); every exception is mapped to a bpg_status and a thread-local message.
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <cstring>
+#include <thread>
 #include <memory>
 #include <string>
 #include "../../include/bpg.h"
@@ -235,6 +237,57 @@ bpg_status bpg_r1cs_verify_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t ts[BPG
         T.export_state(ts);
         if (e != R1CSError::None) throw R1CSException(e, e == R1CSError::VerificationError ? "proof rejected" : e == R1CSError::FormatError ? "malformed proof" : "generator capacity below padded circuit size");
     });
+}
+
+// ---------------------------------------------------------------------------------------- batch pool
+struct bpg_pool { std::vector<bpg_ctx *> ctxs; };
+bpg_status bpg_pool_create(int32_t device, uint32_t workers, uint64_t gens_capacity, bpg_pool **out) {
+    if (!out) return BPG_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (workers < 1 || workers > 64) { g_last_error = "pool: 1..64 workers"; return BPG_ERR_INVALID_ARGUMENT; }
+    bpg_pool *pool = new bpg_pool();
+    for (uint32_t k = 0; k < workers; k++) {
+        bpg_ctx *c = nullptr;
+        bpg_status s = bpg_ctx_create(device, &c);
+        if (s == BPG_OK && gens_capacity) s = bpg_gens_ensure(c, gens_capacity);
+        if (s != BPG_OK) { std::string keep = g_last_error; if (c) bpg_ctx_destroy(c); bpg_pool_destroy(pool); g_last_error = keep; return s; }
+        pool->ctxs.push_back(c);
+    }
+    *out = pool;
+    return BPG_OK;
+}
+void bpg_pool_destroy(bpg_pool *pool) {
+    if (!pool) return;
+    for (bpg_ctx *c : pool->ctxs) bpg_ctx_destroy(c);
+    delete pool;
+}
+bpg_status bpg_pool_prove(bpg_pool *pool, uint64_t count, const bpg_batch_item *items, bpg_status *status_out) {
+    if (!pool || (count && !items)) return BPG_ERR_INVALID_ARGUMENT;
+    std::atomic<uint64_t> next(0);
+    std::vector<bpg_status> st(count, BPG_OK);
+    std::vector<std::string> msg(count);
+    auto work = [&](bpg_ctx *ctx) {
+        for (;;) {
+            const uint64_t i = next.fetch_add(1);
+            if (i >= count) return;
+            const bpg_batch_item &it = items[i];
+            st[i] = (it.inst && it.transcript_state && it.rng_seed && it.proof_out && it.proof_len)
+                        ? bpg_r1cs_prove(ctx, it.inst, it.transcript_state, it.m, it.v_blinding, it.rng_seed, it.flags, it.proof_out, it.proof_len)
+                        : BPG_ERR_INVALID_ARGUMENT;
+            if (st[i] != BPG_OK) msg[i] = g_last_error;            // g_last_error is per thread
+        }
+    };
+    std::vector<std::thread> th;
+    const size_t nthreads = std::min<uint64_t>(pool->ctxs.size(), count);
+    for (size_t k = 1; k < nthreads; k++) th.emplace_back(work, pool->ctxs[k]);
+    if (nthreads) work(pool->ctxs[0]);
+    for (std::thread &t : th) t.join();
+    bpg_status first = BPG_OK;
+    for (uint64_t i = 0; i < count; i++) {
+        if (status_out) status_out[i] = st[i];
+        if (first == BPG_OK && st[i] != BPG_OK) { first = st[i]; g_last_error = "item " + std::to_string(i) + ": " + msg[i]; }
+    }
+    return first;
 }
 
 // ---------------------------------------------------------------------------------------- transcript

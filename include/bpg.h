@@ -108,6 +108,24 @@ bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t 
 bpg_status bpg_r1cs_verify_resident(bpg_ctx *ctx, bpg_circuit *circuit, uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES],
                                     uint64_t m, const uint8_t *V, const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags);
 
+/* A batch of INDEPENDENT proofs on one GPU.  One proof keeps the device busy for ~45 ms of 340 (the rest is the host's serial Merlin
+ * TranscriptRng chain, upstream-exact), so a pool of `workers` engine contexts + host threads proves items concurrently: the chain of
+ * one proof overlaps the kernels of the others (8 workers: ~5x the single-proof rate on a 2^20 circuit).  Each item is what
+ * bpg_r1cs_prove takes; items are independent (own transcript, witness, seed); results are byte-identical to proving them one by
+ * one.  status_out[i] receives the bpg_status of item i; the call returns BPG_OK when every item succeeded, else the first failure. */
+typedef struct bpg_pool bpg_pool;
+typedef struct {
+    const bpg_r1cs_instance *inst;
+    uint8_t *transcript_state;            /* 203 B, updated in place */
+    uint64_t m; const uint8_t *v_blinding;
+    const uint8_t *rng_seed;              /* 32 B */
+    uint32_t flags;
+    uint8_t *proof_out; uint64_t *proof_len;   /* in = capacity, out = bytes written */
+} bpg_batch_item;
+bpg_status bpg_pool_create(int32_t device, uint32_t workers, uint64_t gens_capacity, bpg_pool **out);
+void bpg_pool_destroy(bpg_pool *pool);
+bpg_status bpg_pool_prove(bpg_pool *pool, uint64_t count, const bpg_batch_item *items, bpg_status *status_out);
+
 /* measurement hooks (bench.py): HIP events on the engine's own stream. mode 0 off, 1 = dominant kernel only, 2 = all kernels;
  * report = JSON text {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}} accumulated since the last set. */
 bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);

@@ -542,3 +542,42 @@ def test_random_circuits_match_oracle(ctx, seed):
     while cap < max(inst.n, 1):
         cap *= 2
     check_against_oracle(ctx, p, t, commitments, cap, flags_list=(0, rnd.choice([1, 2, 3])), seed=bytes([seed]) * 32)
+
+
+def test_pool_batch_matches_individual_proofs(ctx):
+    """bpg_pool_prove: a batch of independent instances (different circuits, sizes and dialects) on 4 worker contexts gives the bytes
+    of proving them one by one; a bad item is reported without losing the others."""
+    makers = [lambda: workloads.bounds_check_64(ctx, seed=1), lambda: workloads.mimc_preimage(ctx, nbytes=20, seed=2, label=b"MiMCHash"),
+              lambda: workloads.bounds_check_64(ctx, seed=3), lambda: workloads.mimc_preimage(ctx, nbytes=70, seed=4, label=b"MiMCHash"),
+              lambda: workloads.merkle_full_tree(ctx, leaves=2, seed=5), lambda: workloads.bounds_check_64(ctx, seed=6),
+              lambda: workloads.mimc_preimage(ctx, nbytes=33, seed=7, label=b"MiMCHash")]
+    items, want = [], []
+    for k, mk in enumerate(makers):
+        a = mk()
+        inst = a.prover.instance()
+        flags = k % 4
+        seed = bytes([k + 1]) * 32
+        ctx.gens_ensure(a.gens_capacity)
+        res = ctx.upload(inst)
+        want.append(res.prove(a.transcript.state, inst.v_blinding, seed, flags))
+        res.free()
+        items.append((inst, a.transcript.state, inst.v_blinding, seed, flags))
+    pool = bpg.ProverPool(0, workers=4, gens_capacity=4096)
+    try:
+        got = pool.prove_batch(items)
+        assert got == want
+        assert pool.prove_batch(items[:2]) == want[:2]                 # fewer items than workers
+        assert pool.prove_batch([]) == []
+        bad = list(items)
+        bad[3] = (items[3][0], items[3][1], items[3][2][:-32], items[3][3], items[3][4])     # one blinding factor short -> m mismatch
+        inst3 = items[3][0]
+        saved_m = inst3.m
+        with pytest.raises(bpg.BpgError) as e:
+            inst3.m = saved_m - 1 if saved_m else 0
+            try:
+                pool.prove_batch(bad)
+            finally:
+                inst3.m = saved_m
+        assert "item 3" in str(e.value)
+    finally:
+        pool.close()
