@@ -355,9 +355,15 @@ class FlatInstance:
     def cstruct(self):
         c = R1CSInstance()
         c.n, c.q, c.m, c.nnz, c.ncoef = self.n, self.q, self.m, self.nnz, self.ncoef
-        self._keep = [C.create_string_buffer(x, max(len(x), 1)) for x in (self.aL, self.aR, self.aO, self.coef)]
-        c.aL, c.aR, c.aO, c.coef = [C.cast(k, C.c_void_p).value for k in self._keep]
+        # one set of C buffers per instance, shared by every struct handed out (a struct must never outlive or invalidate another:
+        # a batch holds many structs of the same instance at once)
+        src = (self.aL, self.aR, self.aO, self.coef)
+        if getattr(self, "_cbufs_src", None) is None or any(a is not b for a, b in zip(self._cbufs_src, src)):
+            self._cbufs = [C.create_string_buffer(x, max(len(x), 1)) for x in src]
+            self._cbufs_src = src
+        c.aL, c.aR, c.aO, c.coef = [C.cast(k, C.c_void_p).value for k in self._cbufs]
         c.row_ptr, c.term_var, c.term_coef = self.row_ptr.ctypes.data, self.term_var.ctypes.data, self.term_coef.ctypes.data
+        c._owner = (self, self._cbufs)                       # keeps the buffers alive as long as the struct is
         return c
 
 

@@ -104,18 +104,15 @@ static void view(const FlatCircuit &f, bpg_r1cs_instance *o) {
     o->aL = f.aL.empty() ? nullptr : f.aL.data(); o->aR = f.aR.empty() ? nullptr : f.aR.data(); o->aO = f.aO.empty() ? nullptr : f.aO.data();
     o->row_ptr = f.row_ptr.data(); o->term_var = f.term_var.data(); o->term_coef = f.term_coef.data(); o->coef = f.coef.data();
 }
-static FlatCircuit from_view(const bpg_r1cs_instance *i, bool need_witness = true) {
+static FlatView as_view(const bpg_r1cs_instance *i, bool need_witness, bool drop_witness = false) {
     REQUIRE(i && i->row_ptr && (i->nnz == 0 || (i->term_var && i->term_coef)) && (i->ncoef == 0 || i->coef));
     const bool has_w = i->aL && i->aR && i->aO;
     REQUIRE(i->n == 0 || has_w || !need_witness);
-    FlatCircuit f; f.n = i->n; f.m = i->m;
-    if (has_w) { f.aL.assign(i->aL, i->aL + i->n * 32); f.aR.assign(i->aR, i->aR + i->n * 32); f.aO.assign(i->aO, i->aO + i->n * 32); }
-    f.row_ptr.assign(i->row_ptr, i->row_ptr + i->q + 1);
-    f.term_var.assign(i->term_var, i->term_var + i->nnz); f.term_coef.assign(i->term_coef, i->term_coef + i->nnz);
-    f.coef.assign(i->coef, i->coef + i->ncoef * 32);
-    return f;
+    FlatView v; v.n = i->n; v.m = i->m; v.q = i->q; v.nnz = i->nnz; v.ncoef = i->ncoef;
+    if (has_w && !drop_witness) { v.aL = i->aL; v.aR = i->aR; v.aO = i->aO; }
+    v.row_ptr = i->row_ptr; v.term_var = i->term_var; v.term_coef = i->term_coef; v.coef = i->coef;
+    return v;
 }
-
 extern "C" {
 
 const char *bpg_strerror(bpg_status s) {
@@ -166,7 +163,7 @@ uint64_t bpg_proof_size(uint64_t n, uint32_t flags) {
 bpg_status bpg_r1cs_upload(bpg_ctx *ctx, const bpg_r1cs_instance *inst, bpg_circuit **out) {
     return guard([&] {
         REQUIRE(ctx && out); *out = nullptr;
-        FlatCircuit f = from_view(inst);
+        const FlatView f = as_view(inst, true);                  // no host copy: the instance goes to the device as it is
         DeviceCircuit *dc = ctx->engine->upload(f);
         *out = new bpg_circuit{dc, f.n, f.m};
     });
@@ -214,9 +211,8 @@ bpg_status bpg_r1cs_verify(bpg_ctx *ctx, const bpg_r1cs_instance *inst, uint8_t 
                            const uint8_t *proof, uint64_t proof_len, const uint8_t seed[32], uint32_t flags) {
     return guard([&] {
         REQUIRE(ctx && ts && proof && seed && (m == 0 || V));
-        FlatCircuit f = from_view(inst, false);
+        const FlatView f = as_view(inst, false, true);           // verifier side: no assignments
         if (f.m != m) throw std::invalid_argument("verify: m does not match the instance");
-        f.aL.clear(); f.aR.clear(); f.aO.clear();
         DeviceCircuit *dc = ctx->engine->upload(f);
         Transcript T = Transcript::from_state(ts);
         R1CSError e;

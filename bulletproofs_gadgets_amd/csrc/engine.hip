@@ -91,7 +91,7 @@ struct DeviceCircuit {
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -158,6 +158,24 @@ struct Engine::Impl {
     uint64_t gens_cap = 0;
 
     void msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result);
+    // Host -> device copy of caller-owned pageable memory through two pinned bounce slots.  A direct hipMemcpyAsync from pageable memory
+    // lets the runtime pin the caller's pages for the DMA; several contexts uploading the SAME arrays from different threads (a pool
+    // proving many witnesses of one circuit) then pin and unpin the same pages concurrently, which faulted the GPU.
+    PinBuf stage; hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    void h2d(void *dst, const void *src, size_t bytes) {
+        const size_t SLOT = 8u << 20;
+        stage.ensure(2 * SLOT);
+        for (int k = 0; k < 2; k++) if (!stage_ev[k]) HIPCHK(hipEventCreateWithFlags(&stage_ev[k], hipEventDisableTiming));
+        const uint8_t *s8 = static_cast<const uint8_t *>(src); uint8_t *d8 = static_cast<uint8_t *>(dst);
+        int slot = 0;
+        for (size_t off = 0; off < bytes; off += SLOT, slot ^= 1) {
+            const size_t len = std::min(SLOT, bytes - off);
+            HIPCHK(hipEventSynchronize(stage_ev[slot]));                 // the previous copy out of this slot has finished
+            std::memcpy(stage.as<uint8_t>() + (size_t)slot * SLOT, s8 + off, len);
+            HIPCHK(hipMemcpyAsync(d8 + off, stage.as<uint8_t>() + (size_t)slot * SLOT, len, hipMemcpyHostToDevice, st));
+            HIPCHK(hipEventRecord(stage_ev[slot], st));
+        }
+    }
     void inner_product(Transcript &T, std::vector<uint8_t> &proof, uint64_t n, uint64_t N, const Scalar &yinv, const Scalar &u_ch, const Scalar &w,
                        const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0);
 };
@@ -205,7 +223,8 @@ Engine::~Engine() {
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
                       &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts};
     for (DevBuf *b : bufs) b->release();
-    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release();
+    for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
 }
@@ -454,60 +473,82 @@ void Engine::msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const ui
 }
 
 // ------------------------------------------------------------------------------------------------ circuit upload
-DeviceCircuit *Engine::upload(const FlatCircuit &c) {
+DeviceCircuit *Engine::upload(const FlatView &c) {
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
-    const uint64_t n = c.n, m = c.m, q = c.row_ptr.size() - 1, nnz = c.term_var.size(), ncoef = c.coef.size() / 32;
-    const bool has_witness = !(c.aL.empty() && c.aR.empty() && c.aO.empty() && n > 0);
-    if (has_witness && (c.aL.size() != n * 32 || c.aR.size() != n * 32 || c.aO.size() != n * 32)) throw std::invalid_argument("upload: witness vectors must hold n scalars");
-    if (c.row_ptr.front() != 0 || c.row_ptr.back() != nnz || c.term_coef.size() != nnz) throw std::invalid_argument("upload: malformed CSR");
+    const uint64_t n = c.n, m = c.m, q = c.q, nnz = c.nnz, ncoef = c.ncoef;
+    const bool has_witness = !(!c.aL && !c.aR && !c.aO && n > 0);
+    if (has_witness && n > 0 && (!c.aL || !c.aR || !c.aO)) throw std::invalid_argument("upload: witness vectors must hold n scalars");
+    if (!c.row_ptr || c.row_ptr[0] != 0 || c.row_ptr[q] != nnz || (nnz && (!c.term_var || !c.term_coef)) || (ncoef && !c.coef)) throw std::invalid_argument("upload: malformed CSR");
     if (n >= (1u << 27)) throw std::invalid_argument("upload: too many multipliers");
-    // CSR (by constraint) -> CSC (by variable) on the host; columns: [0,n) left, [n,2n) right, [2n,3n) output, [3n,3n+m) committed,
-    // 3n+m = the constant terms (Variable::One; only the verifier's w_c needs them)
-    const uint64_t ncols = 3 * n + m + 1;
-    std::vector<uint64_t> col_ptr(ncols + 1, 0);
-    auto col_of = [&](uint32_t pv) -> int64_t {
-        uint32_t kind = pv >> 29, idx = pv & 0x1fffffffu;
-        if (kind <= 2) { if (idx >= n) throw std::invalid_argument("upload: multiplier index out of range"); return (int64_t)(kind * n + idx); }
-        if (kind == 3) { if (idx >= m) throw std::invalid_argument("upload: committed index out of range"); return (int64_t)(3 * n + idx); }
-        if (kind == 4) return (int64_t)(3 * n + m);
-        throw std::invalid_argument("upload: bad variable kind");
-    };
+    // validation on the host (one sequential pass), transposition CSR (by constraint) -> CSC (by variable) on the device (k_csc_*);
+    // columns: [0,n) left, [n,2n) right, [2n,3n) output, [3n,3n+m) committed, 3n+m = the constant terms (only the verifier's w_c needs them)
+    const uint64_t ncols = 3 * n + m + 1, nvar = ncols - 1;
+    if (q >= (1ull << 32) || nnz >= (1ull << 32) || ncols >= (1ull << 32)) throw std::invalid_argument("upload: circuit too large");
     for (uint64_t k = 0; k < nnz; k++) {
+        const uint32_t pv = c.term_var[k], kind = pv >> 29, idx = pv & 0x1fffffffu;
         if (c.term_coef[k] >= ncoef) throw std::invalid_argument("upload: coefficient index out of range");
-        int64_t col = col_of(c.term_var[k]); if (col >= 0) col_ptr[col + 1]++;
+        if (kind <= 2) { if (idx >= n) throw std::invalid_argument("upload: multiplier index out of range"); }
+        else if (kind == 3) { if (idx >= m) throw std::invalid_argument("upload: committed index out of range"); }
+        else if (kind != 4) throw std::invalid_argument("upload: bad variable kind");
     }
-    for (uint64_t i = 0; i < ncols; i++) col_ptr[i + 1] += col_ptr[i];
-    const uint64_t kept = col_ptr[ncols];
-    std::vector<uint32_t> ent_row(kept ? kept : 1), ent_coef(kept ? kept : 1);
-    std::vector<uint64_t> fill(col_ptr.begin(), col_ptr.end() - 1);
-    for (uint64_t r = 0; r < q; r++)
-        for (uint64_t k = c.row_ptr[r]; k < c.row_ptr[r + 1]; k++) {
-            int64_t col = col_of(c.term_var[k]); if (col < 0) continue;
-            uint64_t pos = fill[col]++; ent_row[pos] = (uint32_t)r; ent_coef[pos] = c.term_coef[k];
-        }
+    for (uint64_t r = 0; r < q; r++) if (c.row_ptr[r] > c.row_ptr[r + 1]) throw std::invalid_argument("upload: malformed CSR");
     DeviceCircuit *d = new DeviceCircuit();
-    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->nnz = kept; d->has_witness = has_witness; d->const_begin = col_ptr[ncols - 1];
+    d->n = n; d->m = m; d->q = q; d->ncols = ncols; d->has_witness = has_witness;
     try {
         d->aL.ensure((n ? n : 1) * sizeof(scm)); d->aR.ensure((n ? n : 1) * sizeof(scm)); d->aO.ensure((n ? n : 1) * sizeof(scm));
-        d->col_ptr.ensure((ncols + 1) * 8); d->ent_row.ensure(ent_row.size() * 4); d->ent_coef.ensure(ent_coef.size() * 4);
+        d->col_ptr.ensure((ncols + 1) * 8); d->ent_row.ensure((nnz ? nnz : 1) * 4); d->ent_coef.ensure((nnz ? nnz : 1) * 4);
         d->coef.ensure((ncoef ? ncoef : 1) * sizeof(scm));
+        {
+            // the CSR arrays travel as they are; workspace: the MSM sort buffers (no MSM runs on this context during an upload)
+            I.entries.ensure((nnz ? nnz : 1) * 8);                              // term_var | term_coef
+            I.plain.ensure((q + 2) * 8 + 64);                                   // row_ptr
+            I.counts.ensure((std::max<uint64_t>(nvar, q) + 2) * 4); I.starts.ensure((std::max<uint64_t>(nvar, q) + 2) * 4);
+            I.cursor.ensure((std::max<uint64_t>(nvar, q) + 2) * 4); I.heavy.ensure((q + 2) * 4); I.tile_hist.ensure((q + 2) * 4 + 64);
+            const uint32_t nb1 = cdiv(nvar ? nvar : 1, SCAN_CHUNK), nb2 = cdiv(q ? q : 1, SCAN_CHUNK);
+            I.blocksum.ensure((size_t)(std::max(nb1, nb2) + 2) * 4);
+            uint32_t *tv = I.entries.as<uint32_t>(), *tc = tv + (nnz ? nnz : 1);
+            uint64_t *rp = I.plain.as<uint64_t>();
+            uint32_t *rowconst = I.heavy.as<uint32_t>(), *rowconst_start = I.tile_hist.as<uint32_t>();
+            if (nnz) {
+                I.h2d(tv, c.term_var, nnz * 4);
+                I.h2d(tc, c.term_coef, nnz * 4);
+            }
+            I.h2d(rp, c.row_ptr, (q + 1) * 8);
+            HIPCHK(hipMemsetAsync(I.counts.p, 0, (nvar + 1) * 4, I.st));
+            HIPCHK(hipMemsetAsync(rowconst, 0, (q + 1) * 4, I.st));
+            if (q) BPG_LAUNCH(I, k_csc_count, dim3(cdiv(q, 256)), dim3(256), rp, tv, (uint32_t)q, (uint32_t)n, (uint32_t)m, I.counts.as<uint32_t>(), rowconst);
+            // exclusive scans: variable columns -> starts / cursor, constant terms per row -> rowconst_start
+            BPG_LAUNCH(I, k_scan_blocksums, dim3(nb1), dim3(256), I.counts.as<uint32_t>(), (uint32_t)nvar, I.blocksum.as<uint32_t>());
+            BPG_LAUNCH(I, k_scan_top, dim3(1), dim3(64), I.blocksum.as<uint32_t>(), nb1);
+            BPG_LAUNCH(I, k_scan_apply, dim3(nb1), dim3(256), I.counts.as<uint32_t>(), (uint32_t)nvar, I.blocksum.as<uint32_t>(), I.starts.as<uint32_t>(), I.cursor.as<uint32_t>());
+            BPG_LAUNCH(I, k_scan_blocksums, dim3(nb2), dim3(256), rowconst, (uint32_t)q, I.blocksum.as<uint32_t>());
+            BPG_LAUNCH(I, k_scan_top, dim3(1), dim3(64), I.blocksum.as<uint32_t>(), nb2);
+            BPG_LAUNCH(I, k_scan_apply, dim3(nb2), dim3(256), rowconst, (uint32_t)q, I.blocksum.as<uint32_t>(), rowconst_start, I.counts.as<uint32_t>() /* scratch */);
+            I.extras.ensure(16 * sizeof(scm));
+            uint32_t *totals = reinterpret_cast<uint32_t *>(I.extras.as<scm>() + 8);
+            BPG_LAUNCH(I, k_csc_colptr, dim3(cdiv(nvar + 1, 256)), dim3(256), I.starts.as<uint32_t>(), rowconst_start, (uint32_t)nvar, (uint32_t)q, d->col_ptr.as<uint64_t>(), totals);
+            if (q) BPG_LAUNCH(I, k_csc_fill, dim3(cdiv(q, 256)), dim3(256), rp, tv, tc, (uint32_t)q, (uint32_t)n, (uint32_t)m, I.cursor.as<uint32_t>(), rowconst_start,
+                              I.starts.as<uint32_t>() + nvar, d->ent_row.as<uint32_t>(), d->ent_coef.as<uint32_t>());
+            HIPCHK(hipGetLastError());
+            uint32_t h_tot[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h_tot, totals, 8, hipMemcpyDeviceToHost, I.st));
+            HIPCHK(hipStreamSynchronize(I.st));
+            d->const_begin = h_tot[0]; d->nnz = h_tot[1];
+            if (d->nnz != nnz) throw std::logic_error("upload: transposition lost entries");
+        }
         const size_t maxn = std::max<uint64_t>(n, ncoef);
         I.small_sc.ensure((maxn ? maxn : 1) * 32);
-        const std::vector<uint8_t> *src[4] = {&c.aL, &c.aR, &c.aO, &c.coef};
+        const uint8_t *src[4] = {c.aL, c.aR, c.aO, c.coef};
         DevBuf *dst[4] = {&d->aL, &d->aR, &d->aO, &d->coef};
         const uint64_t cnts[4] = {n, n, n, ncoef};
         for (int k = 0; k < 4; k++) {
             if (!cnts[k] || (k < 3 && !has_witness)) continue;
-            HIPCHK(hipMemcpyAsync(I.small_sc.p, src[k]->data(), cnts[k] * 32, hipMemcpyHostToDevice, I.st));
+            I.h2d(I.small_sc.p, src[k], cnts[k] * 32);
             BPG_LAUNCH(I, k_sc_from_bytes, dim3(cdiv(cnts[k], 256)), dim3(256), I.small_sc.as<uint32_t>(), dst[k]->as<scm>(), (uint32_t)cnts[k]);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(I.st));
         }
-        HIPCHK(hipMemcpyAsync(d->col_ptr.p, col_ptr.data(), (ncols + 1) * 8, hipMemcpyHostToDevice, I.st));
-        HIPCHK(hipMemcpyAsync(d->ent_row.p, ent_row.data(), ent_row.size() * 4, hipMemcpyHostToDevice, I.st));
-        HIPCHK(hipMemcpyAsync(d->ent_coef.p, ent_coef.data(), ent_coef.size() * 4, hipMemcpyHostToDevice, I.st));
-        HIPCHK(hipStreamSynchronize(I.st));
     } catch (...) { free_circuit(d); throw; }
     return d;
 }

@@ -37,7 +37,8 @@ public:
     // multiscalar multiplication over generator-table slices, for tests: sum s_i * G[first+i] + t_i * H[first+i]
     void msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
 
-    DeviceCircuit *upload(const FlatCircuit &c);
+    DeviceCircuit *upload(const FlatView &c);
+    DeviceCircuit *upload(const FlatCircuit &c) { return upload(FlatView(c)); }
     void free_circuit(DeviceCircuit *c);
     // Prover::prove on a resident circuit. transcript: state after Prover::new + every "V" append (updated in place).
     std::vector<uint8_t> prove(DeviceCircuit *c, Transcript &transcript, const std::vector<Scalar> &v_blinding,

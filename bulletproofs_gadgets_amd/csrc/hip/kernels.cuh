@@ -243,6 +243,46 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const scm *__restrict__
     if (threadIdx.x == 0) out[k] = r;
 }
 
+// ------------------------------------------------------------------------------------------------ circuit upload: CSR -> CSC on the device
+// The caller's constraint list is row-major (one row per constraint); k_flatten wants it column-major (one column per variable).
+// Column of a term: left / right / output multiplier i -> i, n+i, 2n+i; committed j -> 3n+j; the constant terms (Variable::One) form
+// the last column 3n+m, which can hold O(q) entries: it is laid out by a scan over the rows, never through one hot atomic.
+__device__ __forceinline__ uint32_t csc_col(uint32_t pv, uint32_t n, uint32_t m) {
+    const uint32_t kind = pv >> 29, idx = pv & 0x1fffffffu;
+    return kind <= 2 ? kind * n + idx : (kind == 3 ? 3 * n + idx : 3 * n + m);
+}
+__global__ void __launch_bounds__(256) k_csc_count(const uint64_t *__restrict__ row_ptr, const uint32_t *__restrict__ term_var, uint32_t q, uint32_t n, uint32_t m,
+                                                   uint32_t *__restrict__ counts /* 3n+m, zeroed */, uint32_t *__restrict__ rowconst /* q */) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= q) return;
+    uint32_t rc = 0;
+    for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+        const uint32_t col = csc_col(term_var[k], n, m);
+        if (col == 3 * n + m) rc++; else atomicAdd(&counts[col], 1u);
+    }
+    rowconst[r] = rc;
+}
+// cursor[] = running positions of the variable columns (k_scan_apply), rowconst_start[] = exclusive scan of rowconst
+__global__ void __launch_bounds__(256) k_csc_fill(const uint64_t *__restrict__ row_ptr, const uint32_t *__restrict__ term_var, const uint32_t *__restrict__ term_coef,
+                                                  uint32_t q, uint32_t n, uint32_t m, uint32_t *__restrict__ cursor, const uint32_t *__restrict__ rowconst_start,
+                                                  const uint32_t *__restrict__ var_total /* starts[3n+m] */, uint32_t *__restrict__ ent_row, uint32_t *__restrict__ ent_coef) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= q) return;
+    uint32_t cpos = *var_total + rowconst_start[r];
+    for (uint64_t k = row_ptr[r]; k < row_ptr[r + 1]; k++) {
+        const uint32_t col = csc_col(term_var[k], n, m);
+        const uint32_t pos = col == 3 * n + m ? cpos++ : atomicAdd(&cursor[col], 1u);
+        ent_row[pos] = r; ent_coef[pos] = term_coef[k];
+    }
+}
+// col_ptr (64-bit, 3n+m+2 entries) from the two scans: variable columns, then the constant column
+__global__ void __launch_bounds__(256) k_csc_colptr(const uint32_t *__restrict__ starts /* 3n+m+1 */, const uint32_t *__restrict__ rowconst_start /* q+1 */,
+                                                    uint32_t nvar, uint32_t q, uint64_t *__restrict__ col_ptr, uint32_t *__restrict__ totals /* [0] var, [1] all */) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c <= nvar) col_ptr[c] = starts[c];                      // col_ptr[nvar] = first entry of the constant column
+    if (c == 0) { const uint32_t all = starts[nvar] + rowconst_start[q]; col_ptr[nvar + 1] = all; totals[0] = starts[nvar]; totals[1] = all; }
+}
+
 // flattened_constraints(z): column-major gather. Column c (0..3n+m): w[c] = sum_e coef[ent_coef[e]] * z^(ent_row[e]+1);
 // columns [3n, 3n+m) are the committed variables and come out negated (wV).
 __global__ void __launch_bounds__(256) k_flatten(const uint64_t *__restrict__ col_ptr, const uint32_t *__restrict__ ent_row,

@@ -63,6 +63,20 @@ struct FlatCircuit {
     std::vector<uint8_t> coef;                   // ncoef*32, deduplicated coefficient table
 };
 
+// non-owning view of the same (what crosses the C ABI: bpg_r1cs_instance); witness pointers may be null on the verifier side
+struct FlatView {
+    uint64_t n = 0, m = 0, q = 0, nnz = 0, ncoef = 0;
+    const uint8_t *aL = nullptr, *aR = nullptr, *aO = nullptr;
+    const uint64_t *row_ptr = nullptr;
+    const uint32_t *term_var = nullptr, *term_coef = nullptr;
+    const uint8_t *coef = nullptr;
+    FlatView() {}
+    explicit FlatView(const FlatCircuit &f)
+        : n(f.n), m(f.m), q(f.row_ptr.size() - 1), nnz(f.term_var.size()), ncoef(f.coef.size() / 32),
+          aL(f.aL.empty() ? nullptr : f.aL.data()), aR(f.aR.empty() ? nullptr : f.aR.data()), aO(f.aO.empty() ? nullptr : f.aO.data()),
+          row_ptr(f.row_ptr.data()), term_var(f.term_var.data()), term_coef(f.term_coef.data()), coef(f.coef.data()) {}
+};
+
 // Shared bookkeeping of Prover and Verifier: constraint rows with a coefficient dictionary.
 class CircuitCore {
 protected:
