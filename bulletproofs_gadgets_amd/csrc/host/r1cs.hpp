@@ -85,12 +85,18 @@ protected:
     std::vector<uint32_t> term_var_, term_coef_;
     std::vector<Scalar> coef_;
     std::unordered_map<Scalar, uint32_t, KeyHash> coef_index_;
+    std::pair<Scalar, uint32_t> last_[2] = {{Scalar(), UINT32_MAX}, {Scalar(), UINT32_MAX}};
     void push_row(const LinearCombination &lc) {
         for (auto &t : lc.terms) {
             Scalar c = t.second.is_canonical() ? t.second : t.second.reduced();
-            auto it = coef_index_.find(c);
             uint32_t id;
-            if (it == coef_index_.end()) { id = (uint32_t)coef_.size(); coef_.push_back(c); coef_index_.emplace(c, id); } else id = it->second;
+            if (last_[0].second != UINT32_MAX && c == last_[0].first) id = last_[0].second;           // two-entry memo in front of the hash map
+            else if (last_[1].second != UINT32_MAX && c == last_[1].first) { id = last_[1].second; std::swap(last_[0], last_[1]); }
+            else {
+                auto it = coef_index_.find(c);
+                if (it == coef_index_.end()) { id = (uint32_t)coef_.size(); coef_.push_back(c); coef_index_.emplace(c, id); } else id = it->second;
+                last_[1] = last_[0]; last_[0] = {c, id};
+            }
             term_var_.push_back(t.first.packed()); term_coef_.push_back(id);
         }
         row_ptr_.push_back(term_var_.size());
@@ -163,7 +169,10 @@ public:
             case Variable::Committed: x = &v_[t.first.idx]; break;
             default: x = &ONE; break;
             }
-            acc += t.second * *x;
+            static const Scalar MINUS_ONE = -Scalar::one();
+            if (t.second == ONE) acc += *x;                          // most coefficients of the gadgets are +-1: skip the multiplication
+            else if (t.second == MINUS_ONE) acc -= *x;
+            else acc += t.second * *x;
         }
         return acc;
     }
