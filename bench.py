@@ -100,8 +100,12 @@ def main():
     ap.add_argument("--baseline-leaves", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-profile", action="store_true", help="one extra, untimed step with HIP events around every kernel")
+    ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / CPU legs): "
+                    "the process then launches nothing but the headline's kernels, which is what the rocprofv3 passes of tools/profile_round.sh want")
     ap.add_argument("--in-flight", type=int, default=6, help="secondary measurement: independent proofs in flight on ONE GPU (0 = skip)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline, args.in_flight = True, 0
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +171,7 @@ def main():
         step(999)               # not a step: the first proof of a context sizes its device workspaces (hipMalloc), keep that out of the timed region
     for i in range(args.warmup):
         step(1000 + i)
-    ctx.profile_set(1)          # HIP events around the dominant kernel only (19 launches per proof)
+    ctx.profile_set(1)          # HIP events around the bucket sweep and the generator folds only (13 launches per proof)
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -188,7 +192,7 @@ def main():
         q_total = float(inst.q)
 
     # untimed diagnostics: phase timings and (optionally) every kernel
-    _, _, tm = step(5000, timings=True)
+    tm = None if args.headline_only else step(5000, timings=True)[2]
     kernels = None
     if args.kernel_profile:
         ctx.profile_set(2)
@@ -198,7 +202,7 @@ def main():
 
     # untimed, secondary: the GPU verifier on the same resident circuit and the proof just produced
     verify_info = None
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         coms = b"".join(a.commitments)
         t0 = time.perf_counter()
         rcs = [res.verify(state, coms, last[0]) for _ in range(3)]
@@ -209,7 +213,7 @@ def main():
     # untimed, secondary: the opt-in BPG_FLAG_EXPANDED_BLINDING dialect (s_L, s_R expanded on the GPU from one TranscriptRng draw instead
     # of 2n serial draws - NOT upstream's derivation, so never the headline): what one proof costs once the host chain is gone
     expanded = None
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         res.prove(state, inst.v_blinding, seed_for(7000), bpg.FLAG_EXPANDED_BLINDING)
         t0 = time.perf_counter()
         for i in range(3):
@@ -218,29 +222,45 @@ def main():
         expanded = {"ms_per_proof": dte * 1e3, "value": inst.q / dte, "unit": "constraints/s", "verified": res.verify(state, b"".join(a.commitments), pe[0]) == 0,
                     "note": "BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): opt-in, not upstream's blinding derivation; not the headline"}
     if rank == 0:
-        fold = prof.get("k_fold_points", {"count": 0, "total_ms": 0.0, "alg_bytes": 0.0, "device_bytes": 0.0, "field_mults": 0.0})
-        secs = fold["total_ms"] * 1e-3
-        achieved = fold["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0
-        traffic = None
+        # HIP-event records of the generator-fold kernels and the bucket sweep (profile mode 1); the roofline object describes the one with
+        # the largest share of the timed steps - at 2^20 that is k_fold_points_reg<7>, the first generator fold of every proof
+        traffic_tab = {}
         tfile = ROOT / "profiles" / "pmc_traffic.json"
         if tfile.exists():
             try:
-                # every instantiation of the fold kernel (k_fold_points, k_fold_points_reg<NT>), per launch
-                fam = [v for k, v in json.loads(tfile.read_text()).items() if k.startswith("k_fold_points")]
-                traffic = (sum(v["total_hbm_bytes"] for v in fam) / max(sum(v["launches"] for v in fam), 1)) if fam else None
+                traffic_tab = json.loads(tfile.read_text())
             except Exception:
-                traffic = None
+                traffic_tab = {}
         peak_fm = ctx.bench_fe_mul(2000)
-        roofline = {"bound": "hbm", "kernel": "k_fold_points", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                    "frac": achieved / 8000.0, "traffic": traffic,
-                    "launches": fold["count"], "avg_launch_ms": fold["total_ms"] / max(fold["count"], 1),
-                    "alg_bytes_per_launch": fold["alg_bytes"] / max(fold["count"], 1),
-                    "device_GBps": fold["device_bytes"] / secs / 1e9 if secs > 0 else 0.0,
-                    "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
-                            "k_fold_points = the generator-fold kernel family (k_fold_points_reg<7> for groups of 3 rounds); traffic from profiles/pmc_traffic.json",
-                    "valu": {"unit": "field-mult/s", "achieved": fold["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
-                             "frac": (fold["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
+        # the register fold is a template over the addends per output, 2^r - 1 for a group of r rounds (engine knobs BPG_FOLD_GROUP, BPG_TT_LG)
+        fold_group, tt_lg = int(os.environ.get("BPG_FOLD_GROUP", "3")), int(os.environ.get("BPG_TT_LG", "14"))
+        first_group = min(fold_group, max(a.gens_capacity.bit_length() - 1 - tt_lg, 0))
+        rocprof_name = {"k_fold_points_reg": "k_fold_points_reg<%d>" % ((1 << first_group) - 1)}
+
+        def kernel_roofline(name):
+            k = prof[name]
+            secs = k["total_ms"] * 1e-3
+            launches = max(k["count"], 1)
+            t = traffic_tab.get(rocprof_name.get(name, name))
+            return {"kernel": rocprof_name.get(name, name), "launches": k["count"], "avg_launch_ms": k["total_ms"] / launches,
+                    "alg_bytes_per_launch": k["alg_bytes"] / launches, "achieved": k["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0,
+                    "traffic": t["hbm_bytes_per_launch"] if t else None,
+                    "device_GBps": k["device_bytes"] / secs / 1e9 if secs > 0 else 0.0,
+                    "valu": {"unit": "field-mult/s", "achieved": k["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
+                             "frac": (k["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
                              "peak_source": "k_bench_fe_mul microbenchmark on this device"}}
+        ranked = sorted((n for n in prof if prof[n]["count"]), key=lambda n: -prof[n]["total_ms"])
+        if ranked:
+            dom = kernel_roofline(ranked[0])
+            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
+                        "frac": dom["achieved"] / 8000.0, "traffic": dom["traffic"], "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                        "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "device_GBps": dom["device_GBps"],
+                        "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
+                                "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv); traffic per launch from profiles/pmc_traffic.json",
+                        "valu": dom["valu"], "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
+        else:
+            roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None,
+                        "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
         out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU", "value": q_total * args.steps / elapsed,
                "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

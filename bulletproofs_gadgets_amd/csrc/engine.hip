@@ -89,7 +89,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
@@ -106,7 +106,8 @@ static const char *const kKernelNames[KID_COUNT] = {
 
 struct Engine::Impl {
     hipStream_t st = nullptr;
-    // profiling: mode 0 off, 1 = k_fold_points only (cheap enough for timed regions), 2 = every kernel
+    // profiling: mode 0 off, 1 = the generator-fold kernels and the bucket sweep only (a few launches per proof: cheap enough for
+    // timed regions), 2 = every kernel
     int prof_mode = 0;
     struct ProfRec { int id; hipEvent_t a, b; };
     std::vector<ProfRec> prof_open;
@@ -114,7 +115,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && id == KID_k_fold_points); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_bucket_chunks)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -429,6 +430,9 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
         BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(), buckets.as<ge_ext>(),
                    slotA, slotB, nkeys, lgCH);
+        // roofline bookkeeping: one mixed addition (7 field multiplications) per entry; an entry is a 4-byte index and a point (32 B of
+        // information, 96 B in the device format).  Mub counts zero digits too (probability 2^-c each for full-width scalars).
+        prof_note(KID_k_bucket_chunks, 36.0 * (double)Mub, 100.0 * (double)Mub, 7.0 * (double)Mub);
         BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH, heavy.as<uint32_t>());
         BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, lgCH, heavy.as<uint32_t>());
     }
@@ -712,20 +716,26 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
             FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
             ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            int fold_kid = KID_k_fold_points;
             {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
-                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory)
-                    BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 1 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 3 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 7 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
-                else if (nterms == 15 && !I.fold_from_memory) BPG_LAUNCH_ID(I, KID_k_fold_points, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);
-                else BPG_LAUNCH(I, k_fold_points, grid, block, Gst, Hst, fo, nf, fg);
+                const bool regs = !I.fold_from_memory && (nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15);
+                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
+                    fold_kid = KID_k_fold_points_split;
+                    BPG_LAUNCH_ID(I, fold_kid, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
+                } else if (regs) {
+                    fold_kid = KID_k_fold_points_reg;
+                    if (nterms == 1) BPG_LAUNCH_ID(I, fold_kid, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);
+                    else if (nterms == 3) BPG_LAUNCH_ID(I, fold_kid, k_fold_points_reg<3>, grid, block, Gst, Hst, fo, nf, fg);
+                    else if (nterms == 7) BPG_LAUNCH_ID(I, fold_kid, k_fold_points_reg<7>, grid, block, Gst, Hst, fo, nf, fg);
+                    else BPG_LAUNCH_ID(I, fold_kid, k_fold_points_reg<15>, grid, block, Gst, Hst, fo, nf, fg);
+                } else BPG_LAUNCH(I, k_fold_points, grid, block, Gst, Hst, fo, nf, fg);
             }
             // bookkeeping for the roofline: 2*g_M points read + 2*Mr written at 32 B (information content) resp. 96/128 B (device formats);
-            // field multiplications: 8 per doubling, 7 per mixed addition
-            I.prof_note(KID_k_fold_points, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);
+            // field multiplications: 8 per doubling, 7 per mixed addition (the split variant runs the doublings once per wave of a block)
+            I.prof_note(fold_kid, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr,
+                        2.0 * Mr * (8.0 * (top + 1) * (fold_kid == KID_k_fold_points_split ? (nterms < 4 ? nterms : 4) : 1) + 7.0) + adds_fm);
             BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group

@@ -174,7 +174,7 @@ class Gens:
         return g.raw, h.raw
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # module globals are already torn down at interpreter exit
             lib().orc_gens_free(self.h)
             self.h = None
 

@@ -12,10 +12,10 @@ mkdir -p "$out"
 timeout -k 10 400 python3 bench.py > "$out/${tag}_bench_plain.json" 2> "$out/${tag}_bench_plain.err" || { echo "bench failed"; tail -5 "$out/${tag}_bench_plain.err"; exit 1; }
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --no-cpu-baseline --in-flight 0 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err" || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err" || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
 echo "stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --no-cpu-baseline --in-flight 0 --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err" || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err" || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
 echo "fetch done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --no-cpu-baseline --in-flight 0 --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err" || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err" || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
 echo "write done"
 find "$out" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
