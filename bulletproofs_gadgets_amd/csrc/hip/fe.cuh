@@ -44,18 +44,36 @@ BPG_HD fe fe_fold512(const uint32_t t[16]) {
 // and no zero-extension moves (the row-wise C++ form costs ~190 v_mov_b32 per multiplication because every 32-bit limb has
 // to be widened into the MAD's 64-bit addend pair).  Only column 0 (no carry-in) is overflow-free; in every other column
 // the first product initialises hi with its carry (a column's carry-in can reach ~2^35, and (2^32-1)^2 + 2^35 > 2^64).
-__device__ __forceinline__ void fe_mac_first(uint64_t &lo, uint32_t a, uint32_t b) {
-    uint64_t c;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(lo), "=&s"(c) : "v"(a), "v"(b));
+// One asm block per product column: lo += sum x_j * y_j, hi = the carries out of bit 64.  The compiler pads every asm statement
+// that writes an SGPR with an s_nop; a block per column instead of one per limb product leaves 15 of them in a multiplication
+// instead of 64, which is worth +13 % where one wave per SIMD runs a dependent chain (Horner tails, compressions) and nothing at
+// two waves or more (tools/diag/bench_fe.hip).
+#define BPG_MAC(X, Y, HI) "v_mad_u64_u32 %0, %2, %" X ", %" Y ", %0\n\tv_addc_co_u32_e64 %1, %2, 0, " HI ", %2\n\t"
+__device__ __forceinline__ void fe_col1(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0));
 }
-__device__ __forceinline__ void fe_mac_second(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t b) {
-    uint64_t c;
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2" : "+v"(lo), "=v"(hi), "=&s"(c) : "v"(a), "v"(b));
+__device__ __forceinline__ void fe_col2(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1));
 }
-__device__ __forceinline__ void fe_mac(uint64_t &lo, uint32_t &hi, uint32_t a, uint32_t b) {
-    uint64_t c;
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(lo), "+v"(hi), "=&s"(c) : "v"(a), "v"(b));
+__device__ __forceinline__ void fe_col3(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2));
 }
+__device__ __forceinline__ void fe_col4(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3));
+}
+__device__ __forceinline__ void fe_col5(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") BPG_MAC("11", "12", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4));
+}
+__device__ __forceinline__ void fe_col6(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") BPG_MAC("11", "12", "%1") BPG_MAC("13", "14", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5));
+}
+__device__ __forceinline__ void fe_col7(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") BPG_MAC("11", "12", "%1") BPG_MAC("13", "14", "%1") BPG_MAC("15", "16", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6));
+}
+__device__ __forceinline__ void fe_col8(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1, uint32_t x2, uint32_t y2, uint32_t x3, uint32_t y3, uint32_t x4, uint32_t y4, uint32_t x5, uint32_t y5, uint32_t x6, uint32_t y6, uint32_t x7, uint32_t y7) {
+    uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") BPG_MAC("11", "12", "%1") BPG_MAC("13", "14", "%1") BPG_MAC("15", "16", "%1") BPG_MAC("17", "18", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7));
+}
+#undef BPG_MAC
 // 64-bit product h * 38 in ONE instruction (both halves), and a * a likewise
 __device__ __forceinline__ uint64_t fe_mul38(uint32_t h) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, 38, 0" : "=v"(p), "=s"(c) : "v"(h)); return p; }
 __device__ __forceinline__ uint64_t fe_sqr32(uint32_t a) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, %2, 0" : "=v"(p), "=s"(c) : "v"(a)); return p; }
@@ -82,19 +100,22 @@ __device__ __forceinline__ fe fe_fold512_dev(const uint32_t t[16]) {
 }
 __device__ __forceinline__ fe fe_mul(const fe &a, const fe &b) {
     uint32_t t[16];
-    uint64_t lo = 0; uint32_t hi = 0;
-#pragma unroll
-    for (int k = 0; k < 15; k++) {
-        const int i0 = (k > 7 ? k - 7 : 0), i1 = (k < 7 ? k : 7);
-        hi = 0;
-#pragma unroll
-        for (int i = i0; i <= i1; i++) {
-            if (k == 0) fe_mac_first(lo, a.v[i], b.v[k - i]);                     // no carry-in: cannot overflow
-            else if (i == i0) fe_mac_second(lo, hi, a.v[i], b.v[k - i]);          // carry-in up to ~2^35: may overflow, hi := carry
-            else fe_mac(lo, hi, a.v[i], b.v[k - i]);
-        }
-        t[k] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
-    }
+    uint64_t lo = 0; uint32_t hi;
+    fe_col1(lo, hi, a.v[0], b.v[0]); t[0] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[0], b.v[1], a.v[1], b.v[0]); t[1] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[0], b.v[2], a.v[1], b.v[1], a.v[2], b.v[0]); t[2] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col4(lo, hi, a.v[0], b.v[3], a.v[1], b.v[2], a.v[2], b.v[1], a.v[3], b.v[0]); t[3] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col5(lo, hi, a.v[0], b.v[4], a.v[1], b.v[3], a.v[2], b.v[2], a.v[3], b.v[1], a.v[4], b.v[0]); t[4] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col6(lo, hi, a.v[0], b.v[5], a.v[1], b.v[4], a.v[2], b.v[3], a.v[3], b.v[2], a.v[4], b.v[1], a.v[5], b.v[0]); t[5] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col7(lo, hi, a.v[0], b.v[6], a.v[1], b.v[5], a.v[2], b.v[4], a.v[3], b.v[3], a.v[4], b.v[2], a.v[5], b.v[1], a.v[6], b.v[0]); t[6] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col8(lo, hi, a.v[0], b.v[7], a.v[1], b.v[6], a.v[2], b.v[5], a.v[3], b.v[4], a.v[4], b.v[3], a.v[5], b.v[2], a.v[6], b.v[1], a.v[7], b.v[0]); t[7] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col7(lo, hi, a.v[1], b.v[7], a.v[2], b.v[6], a.v[3], b.v[5], a.v[4], b.v[4], a.v[5], b.v[3], a.v[6], b.v[2], a.v[7], b.v[1]); t[8] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col6(lo, hi, a.v[2], b.v[7], a.v[3], b.v[6], a.v[4], b.v[5], a.v[5], b.v[4], a.v[6], b.v[3], a.v[7], b.v[2]); t[9] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col5(lo, hi, a.v[3], b.v[7], a.v[4], b.v[6], a.v[5], b.v[5], a.v[6], b.v[4], a.v[7], b.v[3]); t[10] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col4(lo, hi, a.v[4], b.v[7], a.v[5], b.v[6], a.v[6], b.v[5], a.v[7], b.v[4]); t[11] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[5], b.v[7], a.v[6], b.v[6], a.v[7], b.v[5]); t[12] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[6], b.v[7], a.v[7], b.v[6]); t[13] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col1(lo, hi, a.v[7], b.v[7]); t[14] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
     t[15] = (uint32_t)lo;
     return fe_fold512_dev(t);
 }
@@ -103,19 +124,20 @@ __device__ __forceinline__ fe fe_sq(const fe &a) {
     // doubled as one 512-bit shift (v_alignbit per limb), and D = sum a_i^2 2^(64 i) added with one carry chain.
     uint32_t u[16];
     u[0] = 0;
-    uint64_t lo = 0; uint32_t hi = 0;
-#pragma unroll
-    for (int k = 1; k < 14; k++) {
-        const int i0 = (k > 7 ? k - 7 : 0);
-        hi = 0;
-#pragma unroll
-        for (int i = i0; 2 * i < k; i++) {
-            if (k == 1) fe_mac_first(lo, a.v[i], a.v[k - i]);
-            else if (i == i0) fe_mac_second(lo, hi, a.v[i], a.v[k - i]);
-            else fe_mac(lo, hi, a.v[i], a.v[k - i]);
-        }
-        u[k] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
-    }
+    uint64_t lo = 0; uint32_t hi;
+    fe_col1(lo, hi, a.v[0], a.v[1]); u[1] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col1(lo, hi, a.v[0], a.v[2]); u[2] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[0], a.v[3], a.v[1], a.v[2]); u[3] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[0], a.v[4], a.v[1], a.v[3]); u[4] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[0], a.v[5], a.v[1], a.v[4], a.v[2], a.v[3]); u[5] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[0], a.v[6], a.v[1], a.v[5], a.v[2], a.v[4]); u[6] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col4(lo, hi, a.v[0], a.v[7], a.v[1], a.v[6], a.v[2], a.v[5], a.v[3], a.v[4]); u[7] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[1], a.v[7], a.v[2], a.v[6], a.v[3], a.v[5]); u[8] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[2], a.v[7], a.v[3], a.v[6], a.v[4], a.v[5]); u[9] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[3], a.v[7], a.v[4], a.v[6]); u[10] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[4], a.v[7], a.v[5], a.v[6]); u[11] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col1(lo, hi, a.v[5], a.v[7]); u[12] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col1(lo, hi, a.v[6], a.v[7]); u[13] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
     u[14] = (uint32_t)lo; u[15] = (uint32_t)(lo >> 32);
     uint32_t t[16], c = 0, co;
 #pragma unroll

@@ -880,7 +880,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
-    uint32_t nmsm, W, nb, lgTile, tmax;
+    uint32_t nmsm, W, nb, lgTile, tmax, lgCH;
     uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
     uint32_t tile_start[5];      // first tile of MSM m
     uint32_t bias[8];
@@ -905,9 +905,11 @@ __global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_
     plain[2 * (size_t)g] = make_uint4(w[0], w[1], w[2], w[3]);
     plain[2 * (size_t)g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
+// pass 1 also notes, for every chunk of 2^lgCH sorted entries, the key of the chunk's first entry (chunk_key): k_bucket_chunks starts
+// from it instead of searching starts[]
 template <int PASS>
 __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
-                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
+                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
     extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
     const uint32_t T = blockIdx.x, win = blockIdx.y;
     uint32_t m = 0;
@@ -933,6 +935,7 @@ __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const ui
         else {
             const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
             const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i;
+            if ((pos & ((1u << P.lgCH) - 1u)) == 0) chunk_key[pos >> P.lgCH] = mw * P.nb + mag - 1;
         }
     }
     if (PASS == 0) {
@@ -1004,30 +1007,33 @@ __device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ s
     return lo - 1;
 }
 __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
-                                                       ge_ext *__restrict__ buckets, ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB,
-                                                       uint32_t nkeys, uint32_t lgCH) {
+                                                       const uint32_t *__restrict__ chunk_key, ge_ext *__restrict__ buckets,
+                                                       ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB, uint32_t nkeys, uint32_t lgCH) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e0 = c << lgCH;
     const uint32_t M = starts[nkeys];                      // true entry count (zero digits were skipped)
     if (e0 >= M) return;
     const uint32_t e1 = (e0 + (1u << lgCH) < M) ? e0 + (1u << lgCH) : M;
-    uint32_t k = msm_bucket_of(starts, nkeys, e0, 0), kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
+    uint32_t k = chunk_key[c], kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
+    uint32_t kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];   // end of the next bucket, loaded one boundary ahead of its use
+    uint32_t ent = entries[e0];
     ge_ext acc = ge_identity();
     for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t sg = (ent >> 27) & 7u, neg = ent >> 31;
+        const ge_niels q = S.pts[sg][msm_point_index(S, sg, ent & 0x07ffffffu)];
+        if (e + 1 < e1) ent = entries[e + 1];
         if (e >= kend) {
             if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
             else { if (seg_begin == e0) slotA[c] = acc; /* a piece ending inside the chunk cannot also end it */ }
             acc = ge_identity(); seg_begin = e;
-            k++; kstart = kend; kend = starts[k + 1];
+            k++; kstart = kend; kend = kend2;
             if (e >= kend) {                                 // a run of empty buckets (half of a 15-bit window is structurally
                 k = msm_bucket_of(starts, nkeys, e, k + 1);  // empty): search instead of walking it with dependent loads
                 kstart = starts[k]; kend = starts[k + 1];
             }
+            kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];
         }
-        const uint32_t ent = entries[e];
-        const uint32_t sg = (ent >> 27) & 7u;
-        const ge_niels q = S.pts[sg][msm_point_index(S, sg, ent & 0x07ffffffu)];
-        acc = ge_madd_signed(acc, q, ent >> 31);
+        acc = ge_madd_signed(acc, q, neg);
     }
     if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
     else { if (seg_begin == e0) slotA[c] = acc; if (kend >= e1) slotB[c] = acc; }
