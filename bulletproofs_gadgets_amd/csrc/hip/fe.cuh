@@ -74,14 +74,16 @@ __device__ __forceinline__ void fe_col8(uint64_t &lo, uint32_t &hi, uint32_t x0,
     uint64_t c; asm(BPG_MAC("3", "4", "0") BPG_MAC("5", "6", "%1") BPG_MAC("7", "8", "%1") BPG_MAC("9", "10", "%1") BPG_MAC("11", "12", "%1") BPG_MAC("13", "14", "%1") BPG_MAC("15", "16", "%1") BPG_MAC("17", "18", "%1") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7));
 }
 #undef BPG_MAC
-// 64-bit product h * 38 in ONE instruction (both halves), and a * a likewise
-__device__ __forceinline__ uint64_t fe_mul38(uint32_t h) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, 38, 0" : "=v"(p), "=s"(c) : "v"(h)); return p; }
-__device__ __forceinline__ uint64_t fe_sqr32(uint32_t a) { uint64_t p, c; asm("v_mad_u64_u32 %0, %1, %2, %2, 0" : "=v"(p), "=s"(c) : "v"(a)); return p; }
 // r = t[0..7] + 38 * t[8..15] (mod p, weakly reduced): 8 MADs and three v_addc chains (__builtin_addc lowers to v_addc_co_u32)
 __device__ __forceinline__ fe fe_fold512_dev(const uint32_t t[16]) {
     uint64_t p[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = fe_mul38(t[8 + i]);
+    {   // the eight products t[8+i] * 38 in one asm block (one trailing s_nop instead of eight)
+        uint64_t c;
+        asm("v_mad_u64_u32 %0, %8, %9, 38, 0\n\tv_mad_u64_u32 %1, %8, %10, 38, 0\n\tv_mad_u64_u32 %2, %8, %11, 38, 0\n\tv_mad_u64_u32 %3, %8, %12, 38, 0\n\t"
+            "v_mad_u64_u32 %4, %8, %13, 38, 0\n\tv_mad_u64_u32 %5, %8, %14, 38, 0\n\tv_mad_u64_u32 %6, %8, %15, 38, 0\n\tv_mad_u64_u32 %7, %8, %16, 38, 0"
+            : "=&v"(p[0]), "=&v"(p[1]), "=&v"(p[2]), "=&v"(p[3]), "=&v"(p[4]), "=&v"(p[5]), "=&v"(p[6]), "=&v"(p[7]), "=&s"(c)
+            : "v"(t[8]), "v"(t[9]), "v"(t[10]), "v"(t[11]), "v"(t[12]), "v"(t[13]), "v"(t[14]), "v"(t[15]));
+    }
     fe r; uint32_t c = 0, co;
 #pragma unroll
     for (int i = 0; i < 8; i++) { r.v[i] = __builtin_addc(t[i], (uint32_t)p[i], c, &co); c = co; }
@@ -139,10 +141,18 @@ __device__ __forceinline__ fe fe_sq(const fe &a) {
     fe_col1(lo, hi, a.v[5], a.v[7]); u[12] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
     fe_col1(lo, hi, a.v[6], a.v[7]); u[13] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
     u[14] = (uint32_t)lo; u[15] = (uint32_t)(lo >> 32);
+    uint64_t dd[8];
+    {   // the eight squares a_i^2, both halves each, in one asm block
+        uint64_t cs;
+        asm("v_mad_u64_u32 %0, %8, %9, %9, 0\n\tv_mad_u64_u32 %1, %8, %10, %10, 0\n\tv_mad_u64_u32 %2, %8, %11, %11, 0\n\tv_mad_u64_u32 %3, %8, %12, %12, 0\n\t"
+            "v_mad_u64_u32 %4, %8, %13, %13, 0\n\tv_mad_u64_u32 %5, %8, %14, %14, 0\n\tv_mad_u64_u32 %6, %8, %15, %15, 0\n\tv_mad_u64_u32 %7, %8, %16, %16, 0"
+            : "=&v"(dd[0]), "=&v"(dd[1]), "=&v"(dd[2]), "=&v"(dd[3]), "=&v"(dd[4]), "=&v"(dd[5]), "=&v"(dd[6]), "=&v"(dd[7]), "=&s"(cs)
+            : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]));
+    }
     uint32_t t[16], c = 0, co;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        const uint64_t d = fe_sqr32(a.v[i]);
+        const uint64_t d = dd[i];
         const uint32_t e0 = (2 * i == 0) ? 0u : __builtin_amdgcn_alignbit(u[2 * i], u[2 * i - 1], 31);     // limb 2i of 2U
         const uint32_t e1 = __builtin_amdgcn_alignbit(u[2 * i + 1], u[2 * i], 31);                        // limb 2i+1 of 2U
         t[2 * i] = __builtin_addc(e0, (uint32_t)d, c, &co); c = co;
