@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../bulletproofs_gadgets_amd/csrc/hip/fe.cuh"
+#include "fe10.cuh"
 using namespace bpg;
+using namespace bpg10;
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "fe_cols.cuh"
 #else
@@ -62,6 +64,53 @@ template <int V> __global__ void __launch_bounds__(256) kb(fe *out, uint32_t ite
     }
     out[t] = fe_add(fe_add(a, b), fe_add(c, d));
 }
+template <int V> __global__ void __launch_bounds__(256) kb10(fe *out, uint32_t iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a8 = FE_D(), b8 = FE_SQRTM1(), c8 = FE_D2(), d8 = FE_ONE_MINUS_D_SQ();
+    a8.v[0] ^= t; b8.v[1] ^= t; c8.v[2] ^= t; d8.v[3] ^= t;
+    a8 = fe_freeze(a8); b8 = fe_freeze(b8); c8 = fe_freeze(c8); d8 = fe_freeze(d8);
+    fe10 a = fe10_from8(a8.v), b = fe10_from8(b8.v), c = fe10_from8(c8.v), d = fe10_from8(d8.v);
+    for (uint32_t i = 0; i < iters; i++) {
+        if (V == 0) { a = fe10_mul(a, b); b = fe10_mul(b, c); c = fe10_mul(c, d); d = fe10_mul(d, a); }
+        if (V == 4) { a = fe10_sq(a); b = fe10_sq(b); c = fe10_sq(c); d = fe10_sq(d); }
+        if (V == 5) { a = fe10_add(a, b); b = fe10_sub(b, c); c = fe10_add(c, d); d = fe10_sub(d, a);
+                      if ((i & 1) == 1) { a = fe10_mul(a, a); b = fe10_mul(b, b); c = fe10_mul(c, c); d = fe10_mul(d, d); } }   // lazy sums need a carrying op now and then
+        if (V == 9) { fe10 x = fe10_mul(a, b); fe10 y = fe10_sq(x); a = fe10_carry(fe10_sub(fe10_add(x, y), a)); b = fe10_mul(fe10_sub(b, x), y); }  // mixed check
+    }
+    // carry, pack, canonical
+    fe10 s4 = fe10_mul(fe10_add(fe10_add(a, b), fe10_add(c, d)), fe10_from8(fe_one().v));
+    // full carry of limb 1 excess
+    uint32_t cy = s4.v[1] >> 25; s4.v[1] &= M25; s4.v[2] += cy; cy = s4.v[2] >> 26; s4.v[2] &= M26; s4.v[3] += cy;
+    fe o; fe10_to8(o.v, s4);
+    out[t] = fe_freeze(o);
+}
+template <int V> __global__ void __launch_bounds__(256) kb8check(fe *out, uint32_t iters) {                 // the same arithmetic in the product's layout
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = FE_D(), b = FE_SQRTM1(), c = FE_D2(), d = FE_ONE_MINUS_D_SQ();
+    a.v[0] ^= t; b.v[1] ^= t; c.v[2] ^= t; d.v[3] ^= t;
+    for (uint32_t i = 0; i < iters; i++) {
+        if (V == 0) { a = fe_mul(a, b); b = fe_mul(b, c); c = fe_mul(c, d); d = fe_mul(d, a); }
+        if (V == 4) { a = fe_sq(a); b = fe_sq(b); c = fe_sq(c); d = fe_sq(d); }
+        if (V == 9) { fe x = fe_mul(a, b); fe y = fe_sq(x); a = fe_sub(fe_add(x, y), a); b = fe_mul(fe_sub(b, x), y); }
+    }
+    out[t] = fe_freeze(fe_add(fe_add(a, b), fe_add(c, d)));
+}
+template <int V> double run10(fe *buf, uint32_t iters, int blocks, double per_iter) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kb10<V>, dim3(blocks), dim3(256), 0, 0, buf, 8u);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(kb10<V>, dim3(blocks), dim3(256), 0, 0, buf, iters);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return (double)blocks * 256 * iters * per_iter / (ms * 1e-3);
+}
+template <int V> int check10(fe *buf) {
+    fe *h0 = new fe[64], *h2 = new fe[64];
+    hipLaunchKernelGGL(kb8check<V>, dim3(1), dim3(64), 0, 0, buf, 7u); hipMemcpy(h0, buf, 64 * sizeof(fe), hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL(kb10<V>, dim3(1), dim3(64), 0, 0, buf, 7u); hipMemcpy(h2, buf, 64 * sizeof(fe), hipMemcpyDeviceToHost);
+    int same = 1; for (int i = 0; i < 64; i++) for (int k = 0; k < 8; k++) same &= h0[i].v[k] == h2[i].v[k];
+    return same;
+}
 template <int V> double run(fe *buf, uint32_t iters, int blocks) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(kb<V>, dim3(blocks), dim3(256), 0, 0, buf, 8u);
@@ -82,6 +131,9 @@ int main() {
     hipLaunchKernelGGL(kb<6>, dim3(1), dim3(64), 0, 0, buf, 5u); hipMemcpy(h2, buf, 64 * sizeof(fe), hipMemcpyDeviceToHost);
     same = 1; for (int i = 0; i < 64; i++) { fe x = fe_freeze(h0[i]), y = fe_freeze(h2[i]); for (int k = 0; k < 8; k++) same &= x.v[k] == y.v[k]; }
     printf("column-block variant equals fe_mul: %d\n", same);
+    printf("radix-2^25.5 prototype equals the 8x32 layout: mul %d  sq %d  mixed %d\n", check10<0>(buf), check10<4>(buf), check10<9>(buf));
+    for (int blocks : {256 * 4, 256 * 8, 256 * 16})
+        printf("blocks %d: fe10 mul4 %.3e  sq4 %.3e  addsub(+1 mul per 4) %.3e ops/s\n", blocks, run10<0>(buf, 2000, blocks, 4.0), run10<4>(buf, 2000, blocks, 4.0), run10<5>(buf, 2000, blocks, 4.0));
     for (int blocks : {256 * 4, 256 * 8, 256 * 16}) {
         printf("blocks %d: mul4chains %.3e  mul1chain %.3e  pair4 %.3e  pair1 %.3e  sq4 %.3e  addsub %.3e  cols4 %.3e\n", blocks,
                run<0>(buf, 2000, blocks), run<1>(buf, 2000, blocks), run<2>(buf, 2000, blocks), run<3>(buf, 2000, blocks), run<4>(buf, 2000, blocks), run<5>(buf, 20000, blocks), run<6>(buf, 2000, blocks));
