@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--leaves", type=int, default=512, help="leaves of the full MiMC Merkle tree (512 = the reference's 2^20 circuit)")
-    ap.add_argument("--baseline-leaves", type=int, default=32)
+    ap.add_argument("--baseline-leaves", type=int, default=64, help="leaves of the CPU-baseline sample tree (64 -> N = 2^17, about 17 s on one core)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-profile", action="store_true", help="one extra, untimed step with HIP events around every kernel")
     ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / CPU legs): "
