@@ -3,6 +3,11 @@
 #include <cstdio>
 #include "../../bulletproofs_gadgets_amd/csrc/hip/fe.cuh"
 #include "fe10.cuh"
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fe10_asm.cuh"
+#else
+__host__ __device__ static inline bpg10::fe10 fe10_mul_asm(const bpg10::fe10 &a, const bpg10::fe10 &) { return a; }
+#endif
 using namespace bpg;
 using namespace bpg10;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -72,6 +77,7 @@ template <int V> __global__ void __launch_bounds__(256) kb10(fe *out, uint32_t i
     fe10 a = fe10_from8(a8.v), b = fe10_from8(b8.v), c = fe10_from8(c8.v), d = fe10_from8(d8.v);
     for (uint32_t i = 0; i < iters; i++) {
         if (V == 0) { a = fe10_mul(a, b); b = fe10_mul(b, c); c = fe10_mul(c, d); d = fe10_mul(d, a); }
+        if (V == 1) { a = fe10_mul_asm(a, b); b = fe10_mul_asm(b, c); c = fe10_mul_asm(c, d); d = fe10_mul_asm(d, a); }
         if (V == 4) { a = fe10_sq(a); b = fe10_sq(b); c = fe10_sq(c); d = fe10_sq(d); }
         if (V == 5) { a = fe10_add(a, b); b = fe10_sub(b, c); c = fe10_add(c, d); d = fe10_sub(d, a);
                       if ((i & 1) == 1) { a = fe10_mul(a, a); b = fe10_mul(b, b); c = fe10_mul(c, c); d = fe10_mul(d, d); } }   // lazy sums need a carrying op now and then
@@ -90,6 +96,7 @@ template <int V> __global__ void __launch_bounds__(256) kb8check(fe *out, uint32
     a.v[0] ^= t; b.v[1] ^= t; c.v[2] ^= t; d.v[3] ^= t;
     for (uint32_t i = 0; i < iters; i++) {
         if (V == 0) { a = fe_mul(a, b); b = fe_mul(b, c); c = fe_mul(c, d); d = fe_mul(d, a); }
+        if (V == 1) { a = fe_mul(a, b); b = fe_mul(b, c); c = fe_mul(c, d); d = fe_mul(d, a); }
         if (V == 4) { a = fe_sq(a); b = fe_sq(b); c = fe_sq(c); d = fe_sq(d); }
         if (V == 9) { fe x = fe_mul(a, b); fe y = fe_sq(x); a = fe_sub(fe_add(x, y), a); b = fe_mul(fe_sub(b, x), y); }
     }
@@ -131,9 +138,9 @@ int main() {
     hipLaunchKernelGGL(kb<6>, dim3(1), dim3(64), 0, 0, buf, 5u); hipMemcpy(h2, buf, 64 * sizeof(fe), hipMemcpyDeviceToHost);
     same = 1; for (int i = 0; i < 64; i++) { fe x = fe_freeze(h0[i]), y = fe_freeze(h2[i]); for (int k = 0; k < 8; k++) same &= x.v[k] == y.v[k]; }
     printf("column-block variant equals fe_mul: %d\n", same);
-    printf("radix-2^25.5 prototype equals the 8x32 layout: mul %d  sq %d  mixed %d\n", check10<0>(buf), check10<4>(buf), check10<9>(buf));
+    printf("radix-2^25.5 prototype equals the 8x32 layout: mul %d  sq %d  mixed %d  hand-scheduled mul %d\n", check10<0>(buf), check10<4>(buf), check10<9>(buf), check10<1>(buf));
     for (int blocks : {256 * 4, 256 * 8, 256 * 16})
-        printf("blocks %d: fe10 mul4 %.3e  sq4 %.3e  addsub(+1 mul per 4) %.3e ops/s\n", blocks, run10<0>(buf, 2000, blocks, 4.0), run10<4>(buf, 2000, blocks, 4.0), run10<5>(buf, 2000, blocks, 4.0));
+        printf("blocks %d: fe10 mul4 %.3e  sq4 %.3e  addsub(+1 mul per 4) %.3e  mul4-asm %.3e ops/s\n", blocks, run10<0>(buf, 2000, blocks, 4.0), run10<4>(buf, 2000, blocks, 4.0), run10<5>(buf, 2000, blocks, 4.0), run10<1>(buf, 2000, blocks, 4.0));
     for (int blocks : {256 * 4, 256 * 8, 256 * 16}) {
         printf("blocks %d: mul4chains %.3e  mul1chain %.3e  pair4 %.3e  pair1 %.3e  sq4 %.3e  addsub %.3e  cols4 %.3e\n", blocks,
                run<0>(buf, 2000, blocks), run<1>(buf, 2000, blocks), run<2>(buf, 2000, blocks), run<3>(buf, 2000, blocks), run<4>(buf, 2000, blocks), run<5>(buf, 20000, blocks), run<6>(buf, 2000, blocks));
