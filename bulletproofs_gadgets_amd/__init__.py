@@ -251,6 +251,11 @@ class Context:
         _chk(lib().bpg_r1cs_upload(self._h, C.byref(cs), C.byref(h)))
         return ResidentCircuit(self, h, inst.n, inst.m)
 
+    def blinding_begin(self, transcript_state, v_blinding, rng_seed, max_multipliers):
+        """bpg_blinding_begin: start the blinding chain of the next prove on this context (state after every "V" append, m x 32 blinding bytes)."""
+        ts = _buf(203); ts.raw = bytes(transcript_state)
+        _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, rng_seed, C.c_uint64(max_multipliers)))
+
     def prove_flat(self, inst: "FlatInstance", transcript_state, v_blinding, rng_seed, flags=0):
         ts = _buf(203); ts.raw = bytes(transcript_state)
         cap = lib().bpg_proof_size(inst.n, flags)
@@ -448,6 +453,11 @@ class Prover:
         _chk(lib().bpg_prover_instance(self._h, C.byref(view), C.byref(v), C.byref(vb)))
         m = view.m
         return FlatInstance(view, v=C.string_at(v, 32 * m) if m else b"", v_blinding=C.string_at(vb, 32 * m) if m else b"")
+
+    def start_blinding(self, rng_seed: bytes = bytes(32), max_multipliers: int = 1 << 20):
+        """Extension (include/bpg.h bpg_prover_start_blinding): all commitments made - start the serial TranscriptRng chain of the coming
+        prove(rng_seed) on a host thread while the constraints are still being assembled. The proof bytes do not change."""
+        _chk(lib().bpg_prover_start_blinding(self._h, rng_seed, C.c_uint64(max_multipliers)))
 
     def prove(self, bp_gens, rng_seed: bytes = bytes(32), flags: int = 0):
         """Prover::prove(&bp_gens) -> R1CSProof::to_bytes(); rng_seed stands in for thread_rng()."""

@@ -68,6 +68,11 @@ std::vector<uint8_t> Prover::prove(uint64_t gens_capacity, const uint8_t rng_see
     } catch (...) { engine_->free_circuit(dc); throw; }
 }
 
+void Prover::start_blinding(const uint8_t rng_seed[32], uint64_t max_multipliers) {
+    if (!engine_) throw DeviceError("this prover has no device context: start_blinding() needs the GPU engine");
+    engine_->blinding_begin(*t_, vb_, rng_seed, max_multipliers);
+}
+
 }  // namespace bpg
 
 // ---------------------------------------------------------------------------------------- handles
@@ -349,6 +354,19 @@ bpg_status bpg_prover_instance(bpg_prover *p, bpg_r1cs_instance *out, const uint
         for (size_t i = 0; i < m; i++) { p->p->v()[i].to_bytes(&p->v_bytes[32 * i]); p->p->v_blinding()[i].to_bytes(&p->vb_bytes[32 * i]); }
         if (v_out) *v_out = p->v_bytes.data();
         if (vb_out) *vb_out = p->vb_bytes.data();
+    });
+}
+
+bpg_status bpg_prover_start_blinding(bpg_prover *p, const uint8_t seed[32], uint64_t max_multipliers) {
+    return guard([&] { REQUIRE(p && seed); p->p->start_blinding(seed, max_multipliers); });
+}
+
+bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, const uint8_t seed[32], uint64_t max_multipliers) {
+    return guard([&] {
+        REQUIRE(ctx && transcript_state && seed && (v_blinding || m == 0));
+        std::vector<Scalar> vb(m);
+        for (uint64_t i = 0; i < m; i++) vb[i] = Scalar::from_bytes_mod_order(v_blinding + 32 * i);
+        ctx->engine->blinding_begin(Transcript::from_state(transcript_state), vb, seed, max_multipliers);
     });
 }
 

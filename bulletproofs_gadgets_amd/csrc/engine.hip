@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include "engine.hpp"
@@ -156,6 +158,26 @@ struct Engine::Impl {
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
     PinBuf h_raw, h_small;
+    // Speculative blinding stream (Engine::blinding_begin): the leading draws of Prover::prove's TranscriptRng, produced on a host thread
+    // before the circuit is known.  snaps[k] = generator state before draw k * SNAP (after the three leading blinding scalars).
+    struct BlindStream {
+        static constexpr uint64_t SNAP = 4096;
+        std::thread th;
+        std::atomic<uint64_t> produced{0};
+        std::atomic<bool> stop{false};
+        uint8_t state[203]; uint8_t seed[32]; std::vector<Scalar> vb;
+        Scalar first[3];
+        std::vector<TranscriptRng> snaps;
+        uint64_t max_draws = 0;
+    };
+    std::unique_ptr<BlindStream> blind;
+    PinBuf h_blind;
+    void blind_cancel() {
+        if (!blind) return;
+        blind->stop.store(true);
+        if (blind->th.joinable()) blind->th.join();
+        blind.reset();
+    }
     uint64_t gens_cap = 0;
 
     void msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result);
@@ -216,15 +238,16 @@ Engine::Engine(int device) : device_(device) {
 
 Engine::~Engine() {
     if (!impl_) return;
+    impl_->blind_cancel();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(impl_->st);
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key};
     for (DevBuf *b : bufs) b->release();
-    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind.release();
     for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
@@ -755,6 +778,40 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
 }
 
 // ------------------------------------------------------------------------------------------------ prove
+// Speculative start of Prover::prove's TranscriptRng (include/bpg.h: bpg_blinding_begin).  The 2n + 3 leading draws depend on the transcript
+// after the last commitment (+ the "m" suffix), the commitment blindings and the external seed - not on the constraints or on n - so a
+// host thread can draw them while the caller still assembles the circuit.  prove() takes the stream over only when all three match.
+void Engine::blinding_begin(const Transcript &after_commitments, const std::vector<Scalar> &v_blinding, const uint8_t seed[32], uint64_t max_multipliers) {
+    HIPCHK(hipSetDevice(device_));
+    Impl &I = *impl_;
+    I.blind_cancel();
+    if (max_multipliers == 0) return;
+    using BS = Impl::BlindStream;
+    auto b = std::make_unique<BS>();
+    Transcript T = after_commitments;
+    T.append_u64("m", v_blinding.size());
+    T.export_state(b->state);
+    std::memcpy(b->seed, seed, 32); b->vb = v_blinding;
+    TranscriptRng rng = T.build_rng(v_blinding, seed);
+    for (int k = 0; k < 3; k++) b->first[k] = rng.random_scalar();
+    b->max_draws = ((2 * max_multipliers + BS::SNAP - 1) / BS::SNAP) * BS::SNAP;
+    I.h_blind.ensure(b->max_draws * 64);
+    b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
+    BS *p = b.get(); uint8_t *raw = I.h_blind.as<uint8_t>();
+    b->th = std::thread([p, raw, rng]() mutable {
+        uint64_t pos = 0;
+        for (;;) {
+            p->snaps[pos / BS::SNAP] = rng;                                  // state before draw pos
+            p->produced.store(pos, std::memory_order_release);               // draws [0, pos) and snapshots up to pos are published
+            if (pos >= p->max_draws || p->stop.load(std::memory_order_relaxed)) break;
+            rng.fill_draws64(raw + 64 * pos, BS::SNAP);
+            pos += BS::SNAP;
+        }
+    });
+    I.blind = std::move(b);
+}
+void Engine::blinding_cancel() { impl_->blind_cancel(); }
+
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
                                    const uint8_t rng_seed[32], uint32_t flags, ProveTimings *tm) {
     HIPCHK(hipSetDevice(device_));
@@ -776,8 +833,20 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
 
     // ---- transcript, RNG, first blindings
     T.append_u64("m", m);
-    TranscriptRng rng = T.build_rng(v_blinding, rng_seed);
-    const Scalar ib = rng.random_scalar(), ob = rng.random_scalar(), sb = rng.random_scalar();
+    const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind
+    // a speculative blinding stream is used only when it was drawn from exactly this transcript state, these blindings and this seed
+    Impl::BlindStream *bs = nullptr;
+    if (I.blind) {
+        uint8_t now[203]; T.export_state(now);
+        const Impl::BlindStream &b = *I.blind;
+        bool ok = !expanded && 2 * n <= b.max_draws && std::memcmp(now, b.state, 203) == 0 && std::memcmp(rng_seed, b.seed, 32) == 0 && b.vb.size() == v_blinding.size();
+        for (size_t i = 0; ok && i < b.vb.size(); i++) ok = std::memcmp(b.vb[i].as_bytes(), v_blinding[i].as_bytes(), 32) == 0;
+        if (ok) bs = I.blind.get(); else I.blind_cancel();
+    }
+    TranscriptRng rng = bs ? bs->snaps[0] : T.build_rng(v_blinding, rng_seed);
+    Scalar ib, ob, sb;
+    if (bs) { ib = bs->first[0]; ob = bs->first[1]; sb = bs->first[2]; }
+    else { ib = rng.random_scalar(); ob = rng.random_scalar(); sb = rng.random_scalar(); }
 
     // small device scalars: extras[0..2] = ib, ob, sb ; [3..4] = cL*w, cR*w (per round)
     I.extras.ensure(16 * sizeof(scm));
@@ -790,7 +859,6 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
 
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
-    const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind
     const bool tabled = I.tt_lg > 0 && N <= (1ull << I.tt_lg) && n > 0;   // the generators have (or get) window tables: A_I, A_O, S are table sums
     if (tabled) I.tt_build(Gtab, Htab, Bn, (uint32_t)N, true);
     const bool merged = expanded || tabled || n < 4096;   // nothing worth hiding: A_I, A_O, S in one pass after the draws (one serial tail, not three)
@@ -836,15 +904,23 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     } else
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
-        uint8_t *raw = I.h_raw.as<uint8_t>();
+        uint8_t *raw = bs ? I.h_blind.as<uint8_t>() : I.h_raw.as<uint8_t>();
         const uint64_t slab = 1u << 16;
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
-            rng.fill_draws64(raw + 64 * i, cnt);
+            if (bs) { while (bs->produced.load(std::memory_order_acquire) < i + cnt) std::this_thread::yield(); }     // drawn (or being drawn) by the stream thread
+            else rng.fill_draws64(raw + 64 * i, cnt);
             HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
             BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
             if (!merged && i + cnt < 2 * n) launch_pieces(i + cnt);
         }
+    }
+    if (bs) {   // take the generator back: the state before draw 2n is the last snapshot at or below it, advanced by the remainder
+        const uint64_t K = (2 * n) / Impl::BlindStream::SNAP, rem = 2 * n - K * Impl::BlindStream::SNAP;
+        while (bs->produced.load(std::memory_order_acquire) < K * Impl::BlindStream::SNAP) std::this_thread::yield();
+        rng = bs->snaps[K];
+        if (rem) { std::vector<uint8_t> skip(rem * 64); rng.fill_draws64(skip.data(), rem); }
+        I.blind_cancel(); bs = nullptr;                    // stops the thread; its pinned buffer stays allocated, the queued uploads still read it
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);

@@ -187,6 +187,8 @@ public:
 
     // Prover::prove(&bp_gens) -> R1CSProof::to_bytes(). rng_seed replaces thread_rng() (32 external bytes).
     std::vector<uint8_t> prove(uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags);
+    // extension: start drawing prove()'s blinding scalars now (all commitments made), while the constraints are still being assembled
+    void start_blinding(const uint8_t rng_seed[32], uint64_t max_multipliers);
 
 private:
     static Scalar red(const Scalar &s) { return s.is_canonical() ? s : s.reduced(); }

@@ -167,6 +167,16 @@ bpg_status bpg_prover_allocate(bpg_prover *p, int32_t has_assignment, const uint
 bpg_status bpg_prover_constrain(bpg_prover *p, const bpg_lc *lc);
 /* borrowed view of the assembled instance (valid until the prover is next mutated or freed) */
 bpg_status bpg_prover_instance(bpg_prover *p, bpg_r1cs_instance *out, const uint8_t **v_out, const uint8_t **v_blinding_out);
+/* Extension (no upstream counterpart; the proof bytes do not change): start drawing the blinding scalars of the coming prove() now.
+ * Upstream's Prover::prove builds its TranscriptRng from the transcript after the last commitment (+ the "m" suffix), the commitment
+ * blindings and thread_rng() - not from the constraints - and then draws 2n + 3 scalars serially (0.30 s of a 0.34 s proof at n = 2^20).
+ * Called once every commitment has been made, this starts that chain on a host thread while the caller keeps assembling constraints;
+ * bpg_prover_prove / bpg_r1cs_prove(_resident) on the same context use the stream iff transcript state, blindings and rng_seed are still
+ * the same and n <= max_multipliers, and silently draw afresh otherwise (another commitment, another seed, BPG_FLAG_EXPANDED_BLINDING).
+ * One stream per context; a second call replaces the first.  max_multipliers sizes a pinned host buffer of 128 bytes per multiplier. */
+bpg_status bpg_prover_start_blinding(bpg_prover *p, const uint8_t rng_seed[32], uint64_t max_multipliers);
+bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES] /* after every "V" append */, uint64_t m,
+                              const uint8_t *v_blinding /* m x 32 */, const uint8_t rng_seed[32], uint64_t max_multipliers);
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags,
                             uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);
 

@@ -581,3 +581,62 @@ def test_pool_batch_matches_individual_proofs(ctx):
         assert "item 3" in str(e.value)
     finally:
         pool.close()
+
+
+def test_speculative_blinding_stream_changes_no_byte(ctx):
+    """bpg_prover_start_blinding / bpg_blinding_begin (extension): the TranscriptRng chain started before the constraints exist gives the
+    same proof as the chain run inside prove(); a stream that no longer matches (another commitment, another seed, too small) is dropped."""
+    seed, other = bytes(range(32)), bytes(range(1, 33))
+    x = bpg.be_to_scalar(bytes.fromhex("0522a64d7b931e"))
+    leaf = bpg.be_to_scalar(bytes.fromhex("0522a64d7b931e21760cf955a15fcc793e8a52b42a56ab03afddec8beb668749"))
+    pat = "(((I I) (I I)) ((I I) (I I)))"
+    probe = bpg.Prover(None, bpg.Transcript(b"probe"))
+    bpg.MerkleTree256(bytes(32), [leaf] * 8, [], pat).prove(probe, [], [])
+    root = probe.instance().aO[-32:]
+
+    def build(early, extra_commit=False, prove_seed=seed, max_mult=1 << 14, flags=0):
+        t = bpg.Transcript(b"stream")
+        p = bpg.Prover(ctx, t)
+        com, var = p.commit(x, bpg.be_to_scalar(b"\x07" * 31))
+        if early:
+            p.start_blinding(seed, max_mult)
+        if extra_commit:
+            p.commit(leaf, bpg.be_to_scalar(b"\x09" * 31))
+        bpg.range_proof(p, var, 56, x)
+        bpg.MerkleTree256(root, [leaf] * 8, [], pat).prove(p, [], [])          # n = 13,608 + 56: the stream crosses several snapshots
+        inst, state = p.instance(), t.state
+        return p.prove(bpg.BulletproofGens(ctx, 1 << 14), prove_seed, flags), inst, state
+
+    og = O.Gens(1 << 14)
+    plain, inst, state = build(False)
+    rc, want, _ = O.prove(og, state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
+    assert rc == 0 and plain == want
+    assert build(True)[0] == plain                                   # stream used
+    assert build(True, max_mult=1000)[0] == plain                    # too small for this circuit: dropped
+    assert build(True, flags=bpg.FLAG_EXPANDED_BLINDING)[0] == build(False, flags=bpg.FLAG_EXPANDED_BLINDING)[0]
+    p2, i2, s2 = build(True, prove_seed=other)                       # proved under another seed: dropped
+    rc, want2, _ = O.prove(og, s2, to_oracle(i2), i2.v_blinding, other, O.FLAG_FAST_MSM)
+    assert rc == 0 and p2 == want2 and p2 != plain
+    p3, i3, s3 = build(True, extra_commit=True)                      # a commitment after the start: dropped
+    rc, want3, _ = O.prove(og, s3, to_oracle(i3), i3.v_blinding, seed, O.FLAG_FAST_MSM)
+    assert rc == 0 and p3 == want3
+    # context-level entry point on resident circuits whose 2n sits on, just past and far below a snapshot boundary (4096 draws)
+    one, zero = (1).to_bytes(32, "little"), bytes(32)
+    for n in (2048, 2049, 1):
+        t = bpg.Transcript(b"stream2")
+        p = bpg.Prover(ctx, t)
+        for i in range(n):
+            p.allocate_multiplier((one, zero) if i & 1 else (zero, one))
+        inst, state = p.instance(), t.state
+        cap = 1
+        while cap < n:
+            cap *= 2
+        ctx.gens_ensure(cap)
+        res = ctx.upload(inst)
+        a, _ = res.prove(state, b"", seed, 0)
+        ctx.blinding_begin(state, b"", seed, cap)
+        b, _ = res.prove(state, b"", seed, 0)
+        c, _ = res.prove(state, b"", seed, 0)                        # stream consumed: plain path again
+        assert a == b == c
+        rc, want, _ = O.prove(O.Gens(cap), state, to_oracle(inst), b"", seed, O.FLAG_FAST_MSM)
+        assert rc == 0 and a == want
