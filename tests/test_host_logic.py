@@ -229,3 +229,14 @@ def test_or_conjunction_assembly_counts_on_the_verifier_side():
     v = bpg.Verifier(bpg.Transcript(b"or"))
     bpg.or_conjunction(v, bpg.ConstraintBuffer(v, False))
     assert (v.instance().n, v.instance().q) == (0, 0)
+
+
+def test_blinding_stream_needs_a_device_context():
+    # the speculative TranscriptRng stream lives in the engine: an assembly-only prover refuses it loudly, a null context is an argument error
+    p = bpg.Prover(None, bpg.Transcript(b"x"))
+    with pytest.raises(bpg.BpgError) as e:
+        p.start_blinding(bytes(32), 1024)
+    assert e.value.status == 7
+    import ctypes as C
+    rc = bpg.lib().bpg_blinding_begin(None, bytes(203), C.c_uint64(0), None, bytes(32), C.c_uint64(16))
+    assert rc != 0 and b"" != bpg.lib().bpg_last_error()
