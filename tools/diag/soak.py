@@ -18,6 +18,15 @@ def job(k, leaves, count, out):
         if i % 7 == 0:                                   # determinism: same seed -> same bytes
             again, _ = res.prove(state, inst.v_blinding, seed, 0)
             if again != proof: bad += 1000
+        if i % 3 == 0:                                   # speculative blinding stream: started early, started for another seed, started and abandoned
+            ctx.blinding_begin(state, inst.v_blinding, seed, a.gens_capacity)
+            if i % 2: time.sleep(0.002 * (i % 5))
+            early, _ = res.prove(state, inst.v_blinding, seed, 0)
+            if early != proof: bad += 100000
+            ctx.blinding_begin(state, inst.v_blinding, hashlib.sha256(seed).digest(), a.gens_capacity)
+            wrong, _ = res.prove(state, inst.v_blinding, seed, 0)
+            if wrong != proof: bad += 1000000
+            ctx.blinding_begin(state, inst.v_blinding, seed, a.gens_capacity)     # left running: the next prove (other seed) or begin drops it
     out[k] = (bad, digest.hexdigest()[:16])
 for leaves, count, nthreads in ((32, 120, 4), (512, 12, 3)):
     out = {}
