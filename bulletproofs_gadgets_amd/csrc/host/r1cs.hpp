@@ -6,6 +6,7 @@
 // Assembly (witness synthesis, LC evaluation, constraint list) stays on the host exactly as in the reference; only
 // commit() and prove() cross the C ABI into the HIP engine.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -25,8 +26,55 @@ struct Variable {
     static Variable unpack(uint32_t p) { return Variable{static_cast<Kind>(p >> 29), p & 0x1fffffffu}; }
 };
 
+// Terms of a linear combination.  Nearly every combination the gadgets build has one to four terms (a MiMC round makes seven of them per
+// multiplier pair), so the first four live inside the object and nothing is allocated; longer ones move to the heap.
+class TermVec {
+public:
+    using value_type = std::pair<Variable, Scalar>;
+    using iterator = value_type *;
+    using const_iterator = const value_type *;
+    TermVec() {}
+    TermVec(const TermVec &o) { append(o.begin(), o.end()); }
+    TermVec(TermVec &&o) noexcept { take(o); }
+    TermVec &operator=(const TermVec &o) { if (this != &o) { n_ = 0; append(o.begin(), o.end()); } return *this; }
+    TermVec &operator=(TermVec &&o) noexcept { if (this != &o) { n_ = 0; heap_.clear(); take(o); } return *this; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    iterator begin() { return data(); }
+    iterator end() { return data() + n_; }
+    const_iterator begin() const { return data(); }
+    const_iterator end() const { return data() + n_; }
+    value_type &operator[](size_t i) { return data()[i]; }
+    const value_type &operator[](size_t i) const { return data()[i]; }
+    void push_back(const value_type &t) { reserve(n_ + 1); data()[n_++] = t; }
+    void emplace_back(const Variable &v, const Scalar &s) { push_back(value_type(v, s)); }
+    template <class It> void insert(const_iterator at, It first, It last) {       // appending only (what LinearCombination needs)
+        if (at != end()) throw std::logic_error("TermVec::insert: only at end()");
+        append(first, last);
+    }
+    void reserve(size_t need) {
+        const size_t cap = heap_.empty() ? INLINE : heap_.size();
+        if (need <= cap) return;
+        std::vector<value_type> h(std::max(need, 2 * cap));
+        std::copy(begin(), end(), h.begin());
+        heap_.swap(h);
+    }
+private:
+    static constexpr size_t INLINE = 4;
+    template <class It> void append(It first, It last) { for (; first != last; ++first) push_back(*first); }
+    void take(TermVec &o) {
+        if (!o.heap_.empty()) heap_.swap(o.heap_); else std::copy(o.inl_, o.inl_ + o.n_, inl_);
+        n_ = o.n_; o.n_ = 0; o.heap_.clear();
+    }
+    value_type *data() { return heap_.empty() ? inl_ : heap_.data(); }
+    const value_type *data() const { return heap_.empty() ? inl_ : heap_.data(); }
+    value_type inl_[INLINE];
+    std::vector<value_type> heap_;
+    size_t n_ = 0;
+};
+
 struct LinearCombination {
-    std::vector<std::pair<Variable, Scalar>> terms;
+    TermVec terms;
     LinearCombination() {}
     LinearCombination(const Variable &v) { terms.emplace_back(v, Scalar::one()); }          // From<Variable>
     LinearCombination(const Scalar &s) { terms.emplace_back(Variable::one(), s); }           // From<Scalar>
