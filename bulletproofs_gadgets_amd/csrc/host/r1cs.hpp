@@ -208,6 +208,7 @@ public:
     Scalar eval(const LinearCombination &lc) const {
         Scalar acc;
         for (auto &t : lc.terms) {
+            if (t.first.kind == Variable::One) { acc += t.second; continue; }     // a constant term: c * 1 (round constants, keys) without the product
             const Scalar *x;
             static const Scalar ONE = Scalar::one();
             switch (t.first.kind) {
