@@ -279,6 +279,10 @@ def main():
                              "frac": (k["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
                              "peak_source": "k_bench_fe_mul microbenchmark on this device"}}
         ranked = sorted((n for n in prof if prof[n]["count"]), key=lambda n: -prof[n]["total_ms"])
+        # the bucket sweep and the first generator fold take the same 29 ms of three proofs to within a per cent: a tie (within 3 %) goes to
+        # the kernel with more launches, so that the line names the same kernel on every run
+        if len(ranked) > 1 and prof[ranked[1]]["total_ms"] > 0.97 * prof[ranked[0]]["total_ms"] and prof[ranked[1]]["count"] > prof[ranked[0]]["count"]:
+            ranked[0], ranked[1] = ranked[1], ranked[0]
         if ranked:
             dom = kernel_roofline(ranked[0])
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
