@@ -1,0 +1,323 @@
+// bucket-method multiscalar multiplication - part of kernels.cuh (included from there, in this order; see its header for the kernel map and the data layout)
+#pragma once
+
+namespace bpg {
+
+// ------------------------------------------------------------------------------------------------ multiscalar multiplication
+// Window j of W covers bits [off(j), off(j+1)) with off(j) = j*254/W: near-equal widths, so that the top window keeps
+// (almost) a full width of entropy - with fixed c-bit windows the last one holds only 253 mod c bits and a handful of
+// buckets would receive every term.  Signed digits: digit j in (-2^(wd-1), 2^(wd-1)], wd = width of window j.
+__device__ __forceinline__ uint32_t msm_off(uint32_t j, uint32_t W) { return (j * 254u) / W; }
+__device__ __forceinline__ int32_t msm_digit(const uint32_t w[8], uint32_t W, uint32_t win, uint32_t &carry) {
+    uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
+    uint64_t two = (uint64_t)(wi < 8 ? w[wi] : 0u) | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+    uint32_t raw = (uint32_t)((two >> sh) & ((1u << wd) - 1u)) + carry;
+    if (raw > (1u << (wd - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << wd); }
+    carry = 0; return (int32_t)raw;
+}
+__device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < BPG_MAX_SEGS; k++) if (k < S.nseg && g >= S.start[k]) s = k;
+    return s;
+}
+
+// Sorting the (term, window) entries by bucket without global atomics (device-scope atomics on MI355X resolve beyond the
+// per-XCD L2 and were the slowest part of the MSM): the terms of each MSM are cut into tiles of 2^lgTile terms; block
+// (tile, window) histograms its tile in LDS (LDS atomics) and writes the row H[msm*W+window][tile][0..nb) with plain coalesced
+// stores; k_msm_tile_prefix turns the rows of one key column into exclusive prefixes over the tiles and emits the bucket
+// totals; after the usual scan of the totals, block (tile, window) reloads its row (+ bucket start) into LDS as cursors and
+// scatters its entries.  key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment.
+// Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
+// field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
+struct MsmPlan {
+    uint32_t nmsm, W, nb, lgTile, tmax, lgCH;
+    uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
+    uint32_t tile_start[5];      // first tile of MSM m
+    uint32_t bias[8];
+};
+__device__ __forceinline__ int32_t msm_digit_biased(const uint32_t w[8], uint32_t W, uint32_t win) {
+    const uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
+    const uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
+    return (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
+}
+__device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, const MsmPlan &P) {
+    sc_to_words(w, sc);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + P.bias[k] + carry; w[k] = (uint32_t)t; carry = t >> 32; }
+}
+// biased plain words of every term, once per MSM (the tile kernels run W times over the same scalars)
+__global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_t total, uint4 *__restrict__ plain) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
+    plain[2 * (size_t)g] = make_uint4(w[0], w[1], w[2], w[3]);
+    plain[2 * (size_t)g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+// pass 1 also notes, for every chunk of 2^lgCH sorted entries, the key of the chunk's first entry (chunk_key): k_bucket_chunks starts
+// from it instead of searching starts[]
+template <int PASS>
+__global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
+                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
+    extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
+    const uint32_t T = blockIdx.x, win = blockIdx.y;
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 4; k++) if (k < P.nmsm && T >= P.tile_start[k]) m = k;
+    const uint32_t t = T - P.tile_start[m];
+    const uint32_t g0 = P.term_start[m] + (t << P.lgTile);
+    const uint32_t g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
+    const uint32_t mw = m * P.W + win;
+    uint32_t *row = H + ((size_t)mw * P.tmax + t) * P.nb;
+    if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = 0;
+    else for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
+    __syncthreads();
+    // the window's bits sit in one or two of the eight words: read only the 16-byte half (or both halves) that holds them
+    const uint32_t off = msm_off(win, P.W), wd = msm_off(win + 1, P.W) - off, wi = off >> 5, sh = off & 31;
+    for (uint32_t g = g0 + threadIdx.x; g < g1; g += 256) {
+        const uint32_t *pw = reinterpret_cast<const uint32_t *>(plain + 2 * (size_t)g);
+        const uint64_t two = (uint64_t)pw[wi] | ((uint64_t)(wi + 1 < 8 ? pw[wi + 1] : 0u) << 32);
+        const int32_t d = (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
+        if (d == 0) continue;
+        const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+        if (PASS == 0) atomicAdd(&tile_lds[mag - 1], 1u);
+        else {
+            const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+            const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i;
+            if ((pos & ((1u << P.lgCH) - 1u)) == 0) chunk_key[pos >> P.lgCH] = mw * P.nb + mag - 1;
+        }
+    }
+    if (PASS == 0) {
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < P.nb; b += 256) row[b] = tile_lds[b];
+    }
+}
+// one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
+__global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys,
+                                                         uint32_t *__restrict__ heavy_count) {
+    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
+    if (key == 0) *heavy_count = 0;                          // list of k_bucket_combine, filled later on this stream
+    if (key >= nkeys) return;
+    const uint32_t mw = key / P.nb, b = key - mw * P.nb, m = mw / P.W;
+    const uint32_t nt = P.tile_start[m + 1] - P.tile_start[m];
+    uint32_t *col = H + (size_t)mw * P.tmax * P.nb + b;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < nt; t++) { const uint32_t v = col[(size_t)t * P.nb]; col[(size_t)t * P.nb] = run; run += v; }
+    counts[key] = run;
+}
+
+// exclusive scan of counts[0..nkeys) in three launches (chunk = 2048 keys per block)
+#define SCAN_CHUNK 2048
+__global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restrict__ counts, uint32_t nkeys, uint32_t *__restrict__ blocksum) {
+    __shared__ uint32_t lds[256];
+    uint32_t base = blockIdx.x * SCAN_CHUNK, s = 0;
+    for (uint32_t k = threadIdx.x; k < SCAN_CHUNK; k += 256) if (base + k < nkeys) s += counts[base + k];
+    lds[threadIdx.x] = s; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d]; __syncthreads(); }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = lds[0];
+}
+__global__ void k_scan_top(uint32_t *__restrict__ blocksum, uint32_t nblocks) {   // single thread: nblocks <= a few thousand
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < nblocks; b++) { uint32_t v = blocksum[b]; blocksum[b] = run; run += v; }
+    blocksum[nblocks] = run;
+}
+__global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ counts, uint32_t nkeys, const uint32_t *__restrict__ blocksum,
+                                                    uint32_t *__restrict__ starts, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t lds[256];
+    uint32_t base = blockIdx.x * SCAN_CHUNK;
+    uint32_t v[8], s = 0;                       // thread owns 8 consecutive keys
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint32_t idx = base + threadIdx.x * 8 + k; v[k] = idx < nkeys ? counts[idx] : 0; s += v[k]; }
+    lds[threadIdx.x] = s; __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {     // inclusive Hillis-Steele scan
+        uint32_t x = threadIdx.x >= d ? lds[threadIdx.x - d] : 0; __syncthreads();
+        lds[threadIdx.x] += x; __syncthreads();
+    }
+    uint32_t run = blocksum[blockIdx.x] + lds[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t idx = base + threadIdx.x * 8 + k;
+        if (idx < nkeys) { starts[idx] = run; cursor[idx] = run; }
+        run += v[k];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) starts[nkeys] = blocksum[gridDim.x];
+}
+
+// Balanced bucket sweep.  The entry list is sorted by bucket (starts[]); thread c adds the points of the fixed-size chunk
+// [c*CH, (c+1)*CH) whatever buckets it crosses, so a bucket that received thousands of terms (identical scalars: the -y^h
+// padding terms of the first IPA round, repeated witness values, range-proof bits) is spread over many threads instead of
+// serialising one.  A bucket that lies inside one chunk is stored directly; a bucket that crosses chunk boundaries leaves
+// one partial per chunk (slotA = piece at the chunk's beginning, slotB = piece at its end) for k_bucket_combine.
+// bucket that holds sorted entry e: the k >= klo with starts[k] <= e < starts[k+1]  (upper_bound - 1)
+__device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ starts, uint32_t nkeys, uint32_t e, uint32_t klo) {
+    uint32_t lo = klo, hi = nkeys + 1;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
+__global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
+                                                       const uint32_t *__restrict__ chunk_key, ge_ext *__restrict__ buckets,
+                                                       ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB, uint32_t nkeys, uint32_t lgCH) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e0 = c << lgCH;
+    const uint32_t M = starts[nkeys];                      // true entry count (zero digits were skipped)
+    if (e0 >= M) return;
+    const uint32_t e1 = (e0 + (1u << lgCH) < M) ? e0 + (1u << lgCH) : M;
+    uint32_t k = chunk_key[c], kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
+    uint32_t kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];   // end of the next bucket, loaded one boundary ahead of its use
+    uint32_t ent = entries[e0];
+    ge_ext acc = ge_identity();
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t sg = (ent >> 27) & 7u, neg = ent >> 31;
+        const ge_niels q = S.pts[sg][msm_point_index(S, sg, ent & 0x07ffffffu)];
+        if (e + 1 < e1) ent = entries[e + 1];
+        if (e >= kend) {
+            if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
+            else { if (seg_begin == e0) slotA[c] = acc; /* a piece ending inside the chunk cannot also end it */ }
+            acc = ge_identity(); seg_begin = e;
+            k++; kstart = kend; kend = kend2;
+            if (e >= kend) {                                 // a run of empty buckets (half of a 15-bit window is structurally
+                k = msm_bucket_of(starts, nkeys, e, k + 1);  // empty): search instead of walking it with dependent loads
+                kstart = starts[k]; kend = starts[k + 1];
+            }
+            kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];
+        }
+        acc = ge_madd_signed(acc, q, neg);
+    }
+    if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
+    else { if (seg_begin == e0) slotA[c] = acc; if (kend >= e1) slotB[c] = acc; }
+}
+
+// one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] for a
+// bucket spread over a few chunks; a bucket spread over more than HEAVY_CHUNKS chunks (thousands of identical scalars: the
+// -y^h padding terms of the first IPA round, repeated witness values) goes on the heavy list for k_bucket_combine_heavy
+#define HEAVY_CHUNKS 32
+__global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
+                                                        const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
+                                                        uint32_t nkeys, uint32_t lgCH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nkeys) return;
+    const uint32_t s0 = starts[k], s1 = starts[k + 1];
+    if (s0 == s1) { buckets[k] = ge_identity(); return; }
+    const uint32_t c0 = s0 >> lgCH, c1 = (s1 - 1) >> lgCH;
+    if (c0 == c1) return;
+    if (c1 - c0 > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
+    ge_ext acc = slotB[c0];
+    for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
+    buckets[k] = acc;
+}
+// one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS
+__global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
+                                                              const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
+                                                              uint32_t lgCH, const uint32_t *__restrict__ heavy) {
+    __shared__ ge_ext lds[256];
+    const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    ge_ext *L = lds + wv * 64;
+    for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {      // wave-uniform trip count; no block barrier inside
+        const uint32_t k = heavy[1 + it];
+        const uint32_t c0 = starts[k] >> lgCH, c1 = (starts[k + 1] - 1) >> lgCH;
+        ge_ext acc = lane == 0 ? slotB[c0] : ge_identity();
+        for (uint32_t c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, slotA[c]);
+        L[lane] = acc;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < d) L[lane] = ge_add(L[lane], L[lane + d]);
+        }
+        if (lane == 0) buckets[k] = L[0];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
+// per (msm, window, segment of SEG buckets): sum_b (b+1) * bucket[b] over the segment -> partial
+__global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__ buckets, ge_ext *__restrict__ partial,
+                                                     uint32_t nb, uint32_t seg, uint32_t nseg_per_win, uint32_t total) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    uint32_t win = t / nseg_per_win, sg = t % nseg_per_win;
+    uint32_t lo = sg * seg;
+    const ge_ext *B = buckets + (size_t)win * nb;
+    ge_ext run = ge_identity(), acc = ge_identity();
+    for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
+    // acc = sum (b - lo + 1) B_b ; add lo * run
+    ge_ext m = ge_identity();
+    for (int32_t k = 15; k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15
+    partial[t] = ge_add(acc, m);
+}
+
+// window sums: one block per (msm, window) adds that window's segment partials (strided loads, LDS tree)
+__global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ partial, ge_ext *__restrict__ wsum, uint32_t nseg_per_win) {
+    __shared__ ge_ext lds[256];
+    const ge_ext *P = partial + (size_t)blockIdx.x * nseg_per_win;
+    ge_ext acc = ge_identity();
+    for (uint32_t s = threadIdx.x; s < nseg_per_win; s += 256) acc = ge_add(acc, P[s]);
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d && threadIdx.x + d < nseg_per_win) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) wsum[blockIdx.x] = lds[0];
+}
+
+// Horner over the window sums, result = sum_j 2^off(j) * S_j: about 250 DEPENDENT doublings, the serial tail of every MSM.
+// One block of 4 waves per MSM; the four independent field products of each doubling / addition step are computed by the
+// four waves concurrently (each wave is on its own SIMD, its lanes all hold the same value) and exchanged through LDS.
+// A single lane needs ~2,600 instructions per doubling; here each wave issues ~1/4 of that between two barriers.
+struct HornerLds { fe c[4]; fe s[4]; };
+__device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv) {
+    // L.c = (X, Y, Z, T) -> doubled point in L.c
+    fe in = (wv == 3) ? fe_add(L.c[0], L.c[1]) : L.c[wv];          // X, Y, Z, X+Y
+    fe sq = fe_sq(in);
+    __syncthreads();
+    L.s[wv] = sq;                                                  // XX, YY, ZZ, (X+Y)^2
+    __syncthreads();
+    fe XX = L.s[0], YY = L.s[1];
+    fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    fe a, b;
+    if (wv == 1) { a = YpX; b = YmX; }                              // Y3 = YpX * YmX
+    else {
+        fe ZZ2 = fe_add(L.s[2], L.s[2]);
+        fe cT = fe_sub(ZZ2, YmX), cX = fe_sub(L.s[3], YpX);
+        if (wv == 0) { a = cX; b = cT; }                            // X3 = cX * cT
+        else if (wv == 2) { a = YmX; b = cT; }                      // Z3 = YmX * cT
+        else { a = cX; b = YpX; }                                   // T3 = cX * YpX
+    }
+    fe r = fe_mul(a, b);
+    L.c[wv] = r;
+    __syncthreads();
+}
+__device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32_t wv) {
+    // L.c += q   (extended + extended, unified formulas)
+    fe X1 = L.c[0], Y1 = L.c[1];
+    fe p;
+    if (wv == 0) p = fe_mul(fe_sub(Y1, X1), fe_sub(q.Y, q.X));      // A
+    else if (wv == 1) p = fe_mul(fe_add(Y1, X1), fe_add(q.Y, q.X)); // B
+    else if (wv == 2) p = fe_mul(fe_mul(L.c[3], q.T), FE_D2());     // C
+    else { p = fe_mul(L.c[2], q.Z); p = fe_add(p, p); }             // D
+    __syncthreads();
+    L.s[wv] = p;
+    __syncthreads();
+    fe A = L.s[0], B = L.s[1], C = L.s[2], D = L.s[3];
+    fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    fe r = (wv == 0) ? fe_mul(E, F) : (wv == 1) ? fe_mul(G, H) : (wv == 2) ? fe_mul(F, G) : fe_mul(E, H);
+    L.c[wv] = r;
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
+    __shared__ HornerLds L;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index, uniform
+    const ge_ext *S = wsum + (size_t)blockIdx.x * W;
+    if (threadIdx.x == 0) { ge_ext t = S[W - 1]; L.c[0] = t.X; L.c[1] = t.Y; L.c[2] = t.Z; L.c[3] = t.T; }
+    __syncthreads();
+    for (int32_t win = (int32_t)W - 2; win >= 0; win--) {
+        const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W);
+        for (uint32_t k = 0; k < shift; k++) horner_dbl(L, wv);
+        const ge_ext q = S[win];
+        horner_add(L, q, wv);
+    }
+    if (threadIdx.x == 0) { ge_ext t; t.X = L.c[0]; t.Y = L.c[1]; t.Z = L.c[2]; t.T = L.c[3]; result[blockIdx.x] = t; }
+}
+
+}  // namespace bpg

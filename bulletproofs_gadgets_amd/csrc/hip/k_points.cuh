@@ -1,0 +1,109 @@
+// generator derivation, normalisation, compression - part of kernels.cuh (included from there, in this order; see its header for the kernel map and the data layout)
+#pragma once
+
+namespace bpg {
+
+// ------------------------------------------------------------------------------------------------ generators
+// one thread per generator: 64 uniform bytes -> Ristretto point (two Elligator maps + add), extended coordinates
+__global__ void __launch_bounds__(256) k_gens_derive(const uint32_t *__restrict__ uniform, ge_ext *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[16];
+    const uint4 *src = reinterpret_cast<const uint4 *>(uniform + 16 * (size_t)i);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { uint4 q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    out[i] = ge_from_uniform_words(w);
+}
+
+// extended -> affine Niels with one field inversion per NORM_K points (Montgomery's trick inside a thread).
+// Thread t handles points t, t+T, t+2T, ... so that loads and stores stay coalesced.
+#define NORM_K 8
+__global__ void __launch_bounds__(256) k_normalize_niels(const ge_ext *__restrict__ in, ge_niels *__restrict__ out, uint32_t count) {
+    uint32_t T = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    fe pre[NORM_K];
+    fe acc = fe_one();
+#pragma unroll
+    for (int k = 0; k < NORM_K; k++) {
+        uint32_t idx = t + k * T;
+        pre[k] = acc;
+        if (idx < count) acc = fe_mul(acc, in[idx].Z);
+    }
+    fe inv = fe_invert(acc);
+#pragma unroll
+    for (int k = NORM_K - 1; k >= 0; k--) {
+        uint32_t idx = t + k * T;
+        if (idx < count) {
+            ge_ext p = in[idx];
+            fe zinv = fe_mul(inv, pre[k]);
+            inv = fe_mul(inv, p.Z);
+            out[idx] = ge_to_niels(p, zinv);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) k_compress(const ge_ext *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_compress(out + 32 * (size_t)i, in[i]);
+}
+// out = in[0] + .. + in[count-1]  (a handful of partial MSM results)
+__global__ void __launch_bounds__(64) k_sum_points(const ge_ext *__restrict__ in, uint32_t count, ge_ext *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ge_ext acc = count ? in[0] : ge_identity();
+    for (uint32_t k = 1; k < count; k++) acc = ge_add(acc, in[k]);
+    *out = acc;
+}
+__global__ void __launch_bounds__(64) k_compress_niels(const ge_niels *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_compress(out + 32 * (size_t)i, ge_madd(ge_identity(), in[i]));
+}
+
+// bases[0] = B, bases[1] = B_blinding = from_uniform(SHA3-512(compress(B))) (hash computed on the host), bases[2] = B + B_blinding
+__global__ void k_init_bases(const uint32_t *__restrict__ hash64, ge_niels *__restrict__ bases) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ge_ext B;
+    B.X = BPG_FE(0x918de5d2u, 0x2f4183e0u, 0xa8a67c6cu, 0x40971ffau, 0x6803537au, 0xdd5bff85u, 0x8cfe80c3u, 0x1063e2ccu);
+    B.Y = BPG_FE(0xf533ad9bu, 0xcc7edf80u, 0x4253df49u, 0x5d14c8bau, 0x0fc4ed5bu, 0x061b3d57u, 0xe44c3c7fu, 0x159a6849u);
+    B.Z = fe_one(); B.T = fe_mul(B.X, B.Y);
+    uint32_t w[16];
+    for (int i = 0; i < 16; i++) w[i] = hash64[i];
+    ge_ext Bb = ge_from_uniform_words(w);
+    ge_ext S = ge_add(B, Bb);
+    bases[0] = ge_to_niels(B, fe_one());
+    bases[1] = ge_to_niels(Bb, fe_invert(Bb.Z));
+    bases[2] = ge_to_niels(S, fe_invert(S.Z));
+}
+
+// unit-test hook for the device field arithmetic (the inline-asm paths cannot be compiled for the host):
+// op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 chain (mixed ops on weakly reduced intermediates); inputs are raw 256-bit values
+__global__ void __launch_bounds__(64) k_test_fe(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint8_t *__restrict__ out, uint32_t n, uint32_t op) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x, y, r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { x.v[k] = a[8 * i + k]; y.v[k] = b[8 * i + k]; }
+    switch (op) {
+    case 0: r = fe_mul(x, y); break;
+    case 1: r = fe_sq(x); break;
+    case 2: r = fe_add(x, y); break;
+    case 3: r = fe_sub(x, y); break;
+    case 4: r = fe_invert(x); break;
+    default:
+        for (int k = 0; k < 25; k++) { fe t = fe_sub(fe_mul(x, y), fe_add(x, y)); x = fe_sq(fe_sub(y, t)); y = fe_add(t, fe_neg(x)); }
+        r = fe_add(x, y); break;
+    }
+    fe_tobytes(out + 32 * (size_t)i, r);
+}
+
+// integer-VALU roofline probe: 4 independent chains of field multiplications per thread, nothing but registers
+__global__ void __launch_bounds__(256) k_bench_fe_mul(fe *__restrict__ out, uint32_t iters) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = FE_D(), b = FE_SQRTM1(), c = FE_D2(), d = FE_ONE_MINUS_D_SQ();
+    a.v[0] ^= t; b.v[1] ^= t; c.v[2] ^= t; d.v[3] ^= t;
+    for (uint32_t i = 0; i < iters; i++) { a = fe_mul(a, b); b = fe_mul(b, c); c = fe_mul(c, d); d = fe_mul(d, a); }
+    out[t] = fe_add(fe_add(a, b), fe_add(c, d));
+}
+
+}  // namespace bpg
