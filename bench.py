@@ -296,7 +296,7 @@ def main():
                         "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
         out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU", "value": q_total * args.steps / elapsed,
                "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "ms_per_step": elapsed / args.steps * 1e3, "gates_per_s": float(inst.n) * world * args.steps / elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
                "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
                                       % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
@@ -318,6 +318,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves)
             out["cpu_baseline"]["host"] = "%d logical CPUs visible; 1 used" % (os.cpu_count() or 0)
+            if out["cpu_baseline"].get("value"):
+                # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
+                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+                out["cpu_baseline"]["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * out["cpu_baseline"]["value"])
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
