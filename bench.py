@@ -4,15 +4,24 @@
 One "step" = one Prover::prove (reference src/bin/prover.rs:93) of the reference's own 2^20 circuit - the full
 512-leaf MiMC Merkle tree of src/merkle_tree/merkle_tree_gadget.rs:473-545 (n = 993,384 multipliers padded to
 N = 2^20, q = 1,986,769 constraints, m = 512 commitments) - with the flattened instance and the generator tables
-already resident in HBM.  N > 1: one process per GPU (torchrun), each rank proves its own independent proof per step
-(weak scaling); the only collective is an RCCL all_gather of the finished proof bytes.
+already resident in HBM.  Steps are independent proofs (own seed): the serial TranscriptRng chain of step i+1 is drawn by
+the context's chain worker (one host thread) while the kernels of step i run; every chain of the K timed steps starts and
+ends inside the timed region.
+
+`--gpus N` (N > 1) without a torchrun environment: this process spawns N ranks itself (fresh child processes, before anything
+touches torch or the GPU) and relays rank 0's line.  Under torchrun it is one rank: one process per GPU, each rank proves its
+own independent proof per step (weak scaling); the only collective is an RCCL all_gather of the finished proof bytes.
+A second, strong-scaling leg proves a fixed batch of 8 independent proofs sharded round-robin over the ranks.
 
 Prints ONE JSON line on rank 0 (see the driver contract); diagnostics go to stderr.
 """
 import argparse
+import hashlib
 import json
 import os
 import pathlib
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,37 +29,144 @@ ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
+METRIC = "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU"
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(ctx, bpg, workloads, leaves, seconds_hint=20.0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--leaves", type=int, default=512, help="leaves of the full MiMC Merkle tree (512 = the reference's 2^20 circuit)")
+    ap.add_argument("--baseline-leaves", type=int, default=512, help="leaves of the CPU-baseline tree (512 = the headline circuit itself, about 150 s on one core; "
+                    "64 -> N = 2^17, about 17 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="draw every chain inside its own prove call (round-1 behaviour): the GPU idles while the host draws")
+    ap.add_argument("--batch", type=int, default=8, help="strong-scaling leg: this many independent proofs in total, sharded round-robin over the ranks (0 = skip)")
+    ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
+    ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / batch / CPU legs): "
+                    "the process then launches nothing but the headline's kernels, which is what the rocprofv3 passes of tools/profile_round.sh want")
+    ap.add_argument("--in-flight", type=int, default=12, help="throughput leg: independent proofs in flight on ONE GPU, one engine context + host thread each (0 = skip)")
+    ap.add_argument("--in-flight-only", action="store_true", help="only the throughput leg (for profiling the concurrent kernel mix)")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------ launcher (N > 1 without torchrun)
+def spawn_ranks(args):
+    """Start `--gpus N` ranks as fresh child processes (python -m torch.distributed.run, rendezvous on 127.0.0.1) BEFORE this process has
+    imported torch or touched the GPU; the children inherit stdout/stderr, so rank 0's JSON line is this command's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py")] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    log("bench.py: spawning %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------ host placement
+def _cpulist(text):
+    out = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.update(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_near_gpu(torch, device_index):
+    """Restrict this rank (and the threads it creates later: the chain worker) to one hardware thread per physical core of the NUMA node
+    its GPU hangs off.  Returns a description for the JSON line; any failure leaves the affinity alone."""
+    info = {"numa_node": None, "cpus_allowed": len(os.sched_getaffinity(0))}
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        info["pci"] = bdf
+        node = int(pathlib.Path("/sys/bus/pci/devices/%s/numa_node" % bdf).read_text())
+        info["numa_node"] = node
+        if node < 0:
+            return info
+        cpus = _cpulist(pathlib.Path("/sys/devices/system/node/node%d/cpulist" % node).read_text()) & os.sched_getaffinity(0)
+        cores = set()
+        for c in cpus:
+            sib = _cpulist(pathlib.Path("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read_text())
+            if c == min(sib & cpus):
+                cores.add(c)
+        if len(cores) >= 2:
+            os.sched_setaffinity(0, cores)
+            info["cpus_allowed"] = len(cores)
+            info["pinned"] = "one thread per core of NUMA node %d" % node
+    except Exception as e:      # noqa: BLE001 - placement is an optimisation, never a reason to fail
+        info["error"] = repr(e)
+    return info
+
+
+def host_description():
+    model = None
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            if line.startswith("Model name:"):
+                model = line.split(":", 1)[1].strip()
+    except Exception:       # noqa: BLE001
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count()}
+
+
+def source_hash():
+    """Hash of the product sources the kernels are built from: a stored PMC profile is only quoted when it was taken from these sources."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "bulletproofs_gadgets_amd" / "csrc").rglob("*")):
+        if p.is_file() and p.suffix in (".hip", ".cuh", ".hpp", ".inc", ".cpp"):
+            h.update(p.name.encode()); h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------ secondary legs
+def cpu_baseline(ctx, bpg, workloads, leaves, headline):
     """Time the single-threaded CPU oracle (upstream's algorithms: constant-time Straus for A_I/A_O/S/T, Straus/Pippenger for
-    L/R, two-point folds) on a bounded sample of the same workload: a smaller full MiMC Merkle tree."""
+    L/R, two-point folds), built with -march=native on this host, on a full MiMC Merkle tree - by default the headline circuit itself."""
     import oracle_lib as O
-    a = workloads.merkle_full_tree(ctx, leaves=leaves, seed=7)
-    inst = a.prover.instance()
+    lib_used = O.use_native()
+    if headline is not None and leaves == headline["leaves"]:
+        a, inst, res = headline["a"], headline["inst"], headline["res"]
+        own = False
+    else:
+        a = workloads.merkle_full_tree(ctx, leaves=leaves, seed=7)
+        inst = a.prover.instance()
+        ctx.gens_ensure(a.gens_capacity)
+        res = ctx.upload(inst)
+        own = True
     oc = O.FlatCircuit(inst.n, inst.m, inst.aL, inst.aR, inst.aO, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
-    g = O.Gens(a.gens_capacity)
     t0 = time.perf_counter()
-    rc, proof, _ = O.prove(g, a.transcript.state, oc, inst.v_blinding, bytes(32), 0)
+    g = O.Gens(a.gens_capacity)
+    t_gens = time.perf_counter() - t0
+    seed = bytes(range(32))
+    t0 = time.perf_counter()
+    rc, proof, _ = O.prove(g, a.transcript.state, oc, inst.v_blinding, seed, 0)
     dt = time.perf_counter() - t0
     assert rc == 0
     # the same instance through the GPU must give the same bytes (keeps the baseline honest about what it computes)
-    ctx.gens_ensure(a.gens_capacity)
-    res = ctx.upload(inst)
-    gp, _ = res.prove(a.transcript.state, inst.v_blinding, bytes(32), 0)
-    res.free()
-    assert gp == proof, "cpu_baseline sample: GPU and oracle proofs differ"
+    gp, _ = res.prove(a.transcript.state, inst.v_blinding, seed, 0)
+    if own:
+        res.free()
+    assert gp == proof, "cpu_baseline: GPU and oracle proofs differ"
     return {"value": inst.q / dt, "unit": "constraints/s", "cores": 1, "kind": "port",
-            "sample": "oracle (single thread, upstream algorithms) on a full %d-leaf MiMC Merkle tree: n=%d, N=%d, q=%d, %.1f s; "
-                      "same instance proved on the GPU byte-identically" % (leaves, inst.n, a.gens_capacity, inst.q, dt),
-            "seconds": dt}
+            "sample": "oracle (single thread, upstream algorithms, -O3 -march=native on this host) on the full %d-leaf MiMC Merkle tree: n=%d, N=%d, q=%d, "
+                      "%.1f s prove (generators %.1f s, not counted); the same instance proved on the GPU byte-identically"
+                      % (leaves, inst.n, a.gens_capacity, inst.q, dt, t_gens),
+            "seconds": dt, "library": os.path.basename(lib_used), "full_size": leaves == 512}
 
 
 def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, steps):
-    """Secondary figure (never `value`): B independent proofs in flight on one GPU, one engine context + host thread each.
+    """Throughput figure (never `value`): B independent proofs in flight on one GPU, one engine context + host thread each.
     The serial TranscriptRng chain of one proof then overlaps the kernels of the others."""
     import threading
     ctxs, ress = [ctx0], [res0]
@@ -88,7 +204,7 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
     if errs:
         raise RuntimeError(errs[0])
     return {"proofs_in_flight": n_ctx, "proofs": n_ctx * steps, "seconds": dt, "value": inst.q * n_ctx * steps / dt,
-            "unit": "constraints/s", "note": "independent proofs per GPU, one engine context and host thread each; not the headline"}
+            "ms_per_proof": dt / (n_ctx * steps) * 1e3, "unit": "constraints/s"}
 
 
 def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
@@ -120,48 +236,44 @@ def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
     return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--leaves", type=int, default=512, help="leaves of the full MiMC Merkle tree (512 = the reference's 2^20 circuit)")
-    ap.add_argument("--baseline-leaves", type=int, default=64, help="leaves of the CPU-baseline sample tree (64 -> N = 2^17, about 17 s on one core)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-profile", action="store_true", help="one extra, untimed step with HIP events around every kernel")
-    ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / CPU legs): "
-                    "the process then launches nothing but the headline's kernels, which is what the rocprofv3 passes of tools/profile_round.sh want")
-    ap.add_argument("--in-flight", type=int, default=6, help="secondary measurement: independent proofs in flight on ONE GPU (0 = skip)")
-    args = ap.parse_args()
-    if args.headline_only:
-        args.no_cpu_baseline, args.in_flight = True, 0
-
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(args):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU, or let bench.py spawn them: run it without torchrun)" % (args.gpus, world))
     # BPG_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer GPUs than ranks (ranks then share devices and the proof bytes
     # travel over gloo on CPU tensors); the driver's runs use the default: one rank per GPU, RCCL ("nccl")
     backend = os.environ.get("BPG_BENCH_BACKEND", "nccl")
     coll_device = "cuda" if backend == "nccl" else "cpu"
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        raise SystemExit("bench.py needs an AMD GPU: the product has no CPU path")
     if world > 1:
         import torch.distributed as dist
-        ndev = torch.cuda.device_count()
-        if backend != "nccl" and ndev:
-            local_rank %= ndev
-        torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if world > ndev:
+                raise SystemExit("bench.py: %d ranks but %d GPUs; one rank per GPU over RCCL (set BPG_BENCH_BACKEND=gloo to rehearse on fewer GPUs)" % (world, ndev))
+            device_index = local_rank
+        else:
+            device_index = local_rank % ndev
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
     else:
         dist = None
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an AMD GPU: the product has no CPU path")
+        device_index = 0
+    placement = pin_near_gpu(torch, device_index)          # before the library creates its threads
 
     import bulletproofs_gadgets_amd as bpg
     from bulletproofs_gadgets_amd import workloads
-    ctx = bpg.Context(local_rank)
+    from bulletproofs_gadgets_amd.batch import gather_proofs, shard_indices
+    ctx = bpg.Context(device_index)
     t0 = time.perf_counter()
     a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=None if rank == 0 else rank)
     inst = a.prover.instance()
@@ -176,9 +288,11 @@ def main():
     if rank == 0:
         log("workload: full %d-leaf MiMC Merkle tree n=%d N=%d q=%d m=%d | assembly+commit %.2fs gens %.2fs upload %.2fs"
             % (args.leaves, inst.n, a.gens_capacity, inst.q, inst.m, t_asm, t_gens, t_up))
+    proof_len = bpg.lib().bpg_proof_size(inst.n, 0)
+    prefetch = not args.no_prefetch
 
     def seed_for(step):
-        return bytes([rank & 0xff, step & 0xff]) + bytes(30)
+        return bytes([rank & 0xff, step & 0xff, (step >> 8) & 0xff]) + bytes(29)
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,52 +300,110 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from bulletproofs_gadgets_amd.batch import gather_proofs
-    proof_len = bpg.lib().bpg_proof_size(inst.n, 0)
+    def prove_sequence(seeds, gather_each=True):
+        """Independent proofs, one after the other on this rank's context.  With prefetch the chain of proof i+1 is queued on the chain
+        worker before proof i is proved (bpg_blinding_begin: same bytes as drawing it inside prove); no chain outlives the sequence."""
+        outs = []
+        if prefetch and seeds:
+            ctx.blinding_begin(state, inst.v_blinding, seeds[0], inst.n)
+        for i, s in enumerate(seeds):
+            if prefetch and i + 1 < len(seeds):
+                ctx.blinding_begin(state, inst.v_blinding, seeds[i + 1], inst.n)
+            out = res.prove(state, inst.v_blinding, s, 0)
+            if dist is not None and gather_each:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
+                proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
+                assert len(proofs) == world
+            outs.append(out)
+        return outs
 
-    def step(i, timings=False):
-        out = res.prove(state, inst.v_blinding, seed_for(i), 0, timings=timings)
-        if dist is not None:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
-            proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
-            assert len(proofs) == world
+    def allreduce(value, op):
+        if dist is None:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    def gather_objects(obj):
+        if dist is None:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj)
         return out
 
-    if args.warmup == 0:
-        step(999)               # not a step: the first proof of a context sizes its device workspaces (hipMalloc), keep that out of the timed region
-    for i in range(args.warmup):
-        step(1000 + i)
+    def collect_profile():
+        prof = ctx.profile_report()
+        ctx.profile_set(0)
+        return prof
+
+    if args.in_flight_only:
+        res.prove(state, inst.v_blinding, seed_for(999), 0)
+        out = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, max(args.in_flight, 2), max(2, args.steps))
+        if rank == 0:
+            print(json.dumps({"in_flight": out}), flush=True)
+        return
+
+    # ---- warm-up (not steps: the first proof of a context sizes its device workspaces), then EXACTLY `steps` timed proofs
+    prove_sequence([seed_for(2000 + i) for i in range(max(args.warmup, 1))])
     ctx.profile_set(1)          # HIP events around the bucket sweep and the generator folds only (13 launches per proof)
     barrier()
     t0 = time.perf_counter()
-    last = None
-    for i in range(args.steps):
-        last = step(i)
+    outs = prove_sequence([seed_for(i) for i in range(args.steps)])
     barrier()
-    elapsed = time.perf_counter() - t0
-    prof = ctx.profile_report()
-    ctx.profile_set(0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        qq = torch.tensor([float(inst.q)], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(qq, op=dist.ReduceOp.SUM)
-        q_total = float(qq.item())
-    else:
-        q_total = float(inst.q)
+    elapsed_local = time.perf_counter() - t0
+    prof = collect_profile()
+    elapsed = allreduce(elapsed_local, dist.ReduceOp.MAX if dist else None)
+    q_total = allreduce(float(inst.q), dist.ReduceOp.SUM if dist else None)
+    chain_cpu = ctx.chain_cpu()
+    ranks_seen = gather_objects({"rank": rank, "device": device_index, "pci": placement.get("pci"), "numa_node": placement.get("numa_node"),
+                                 "cpus_allowed": placement.get("cpus_allowed"), "chain_cpu": chain_cpu, "main_cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else None,
+                                 "ms_per_step": elapsed_local / args.steps * 1e3})
+    last = outs[-1]
 
-    # untimed diagnostics: phase timings and (optionally) every kernel
-    tm = None if args.headline_only else step(5000, timings=True)[2]
-    kernels = None
-    if args.kernel_profile:
+    # ---- strong-scaling leg: a fixed batch of independent proofs, sharded round-robin over the ranks (north_star: 8 proofs, >= 6x at 8 GPUs)
+    batch_info = None
+    if args.batch > 0 and not args.headline_only:
+        mine = shard_indices(args.batch, rank, world)
+        barrier()
+        t0 = time.perf_counter()
+        bouts = prove_sequence([seed_for(3000 + i) for i in mine], gather_each=False)
+        local = {i: o[0] for i, o in zip(mine, bouts)}
+        if dist is not None:
+            allp = gather_proofs(local, args.batch, proof_len, dist, device=coll_device)
+        else:
+            allp = [local[i] for i in range(args.batch)]
+        barrier()
+        dtb = allreduce(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
+        assert len(allp) == args.batch and all(len(p) == proof_len for p in allp)
+        batch_info = {"proofs": args.batch, "ranks": world, "proofs_per_rank": len(shard_indices(args.batch, 0, world)), "seconds": dtb,
+                      "value": float(inst.q) * args.batch / dtb, "unit": "constraints/s", "scaling": "strong",
+                      "note": "fixed batch of independent 2^20 proofs, proof i on rank i mod N, one chain thread per rank (the reference: one prover process per "
+                              "proof, src/bin/prover.rs:47-100); speed-up = seconds at N=1 / seconds at N"}
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---------------------------------------------------------------- rank 0: untimed diagnostics and secondary figures
+    tm = kernels = None
+    latency_ms = None
+    gpu_ms_per_proof = None
+    if not args.headline_only:
+        # one proof alone, its chain drawn inside the call (what a single cold request costs), with phase timings
+        t0 = time.perf_counter()
+        alone = res.prove(state, inst.v_blinding, seed_for(0), 0, timings=True)
+        latency_ms = (time.perf_counter() - t0) * 1e3
+        tm = alone[2]
+        if alone[0] != outs[0][0]:
+            raise RuntimeError("the pipelined step and the stand-alone proof of the same seed differ")
         ctx.profile_set(2)
-        step(5001)
-        kernels = ctx.profile_report()
-        ctx.profile_set(0)
+        res.prove(state, inst.v_blinding, seed_for(5001), 0)
+        kernels = collect_profile()
+        gpu_ms_per_proof = sum(v["total_ms"] for v in kernels.values())
 
-    # untimed, secondary: the GPU verifier on the same resident circuit and the proof just produced
     verify_info = None
-    if rank == 0 and not args.headline_only:
+    if not args.headline_only:
         coms = b"".join(a.commitments)
         t0 = time.perf_counter()
         rcs = [res.verify(state, coms, last[0]) for _ in range(3)]
@@ -239,10 +411,8 @@ def main():
         bad = bytearray(last[0]); bad[70] ^= 1
         verify_info = {"ms": dtv * 1e3, "accepted": all(r == 0 for r in rcs), "tampered_rejected": res.verify(state, coms, bytes(bad)) != 0,
                        "note": "bpg_r1cs_verify_resident: transcript replay on the host + one (2N+m+2lgN+13)-term MSM; not the headline"}
-    # untimed, secondary: the opt-in BPG_FLAG_EXPANDED_BLINDING dialect (s_L, s_R expanded on the GPU from one TranscriptRng draw instead
-    # of 2n serial draws - NOT upstream's derivation, so never the headline): what one proof costs once the host chain is gone
     expanded = None
-    if rank == 0 and not args.headline_only:
+    if not args.headline_only:
         res.prove(state, inst.v_blinding, seed_for(7000), bpg.FLAG_EXPANDED_BLINDING)
         t0 = time.perf_counter()
         for i in range(3):
@@ -250,82 +420,123 @@ def main():
         dte = (time.perf_counter() - t0) / 3
         expanded = {"ms_per_proof": dte * 1e3, "value": inst.q / dte, "unit": "constraints/s", "verified": res.verify(state, b"".join(a.commitments), pe[0]) == 0,
                     "note": "BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): opt-in, not upstream's blinding derivation; not the headline"}
-    if rank == 0:
-        # HIP-event records of the generator-fold kernels and the bucket sweep (profile mode 1); the roofline object describes the one with
-        # the largest share of the timed steps - at 2^20 that is k_fold_points_reg<7>, the first generator fold of every proof
-        traffic_tab = {}
-        tfile = ROOT / "profiles" / "pmc_traffic.json"
-        if tfile.exists():
-            try:
-                traffic_tab = json.loads(tfile.read_text())
-            except Exception:
-                traffic_tab = {}
-        peak_fm = ctx.bench_fe_mul(2000)
-        # the register fold is a template over the addends per output, 2^r - 1 for a group of r rounds (engine knobs BPG_FOLD_GROUP, BPG_TT_LG)
-        fold_group, tt_lg = int(os.environ.get("BPG_FOLD_GROUP", "3")), int(os.environ.get("BPG_TT_LG", "14"))
-        first_group = min(fold_group, max(a.gens_capacity.bit_length() - 1 - tt_lg, 0))
-        rocprof_name = {"k_fold_points_reg": "k_fold_points_reg<%d>" % ((1 << first_group) - 1)}
 
-        def kernel_roofline(name):
-            k = prof[name]
-            secs = k["total_ms"] * 1e-3
-            launches = max(k["count"], 1)
-            t = traffic_tab.get(rocprof_name.get(name, name))
-            return {"kernel": rocprof_name.get(name, name), "launches": k["count"], "avg_launch_ms": k["total_ms"] / launches,
-                    "alg_bytes_per_launch": k["alg_bytes"] / launches, "achieved": k["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0,
-                    "traffic": t["hbm_bytes_per_launch"] if t else None,
-                    "device_GBps": k["device_bytes"] / secs / 1e9 if secs > 0 else 0.0,
-                    "valu": {"unit": "field-mult/s", "achieved": k["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
-                             "frac": (k["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
-                             "peak_source": "k_bench_fe_mul microbenchmark on this device"}}
-        ranked = sorted((n for n in prof if prof[n]["count"]), key=lambda n: -prof[n]["total_ms"])
-        # the bucket sweep and the first generator fold take the same 29 ms of three proofs to within a per cent: a tie (within 3 %) goes to
-        # the kernel with more launches, so that the line names the same kernel on every run
-        if len(ranked) > 1 and prof[ranked[1]]["total_ms"] > 0.97 * prof[ranked[0]]["total_ms"] and prof[ranked[1]]["count"] > prof[ranked[0]]["count"]:
-            ranked[0], ranked[1] = ranked[1], ranked[0]
-        if ranked:
-            dom = kernel_roofline(ranked[0])
-            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
-                        "frac": dom["achieved"] / 8000.0, "traffic": dom["traffic"], "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
-                        "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "device_GBps": dom["device_GBps"],
-                        "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
-                                "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv); traffic per launch from profiles/pmc_traffic.json",
-                        "valu": dom["valu"], "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
-        else:
-            roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None,
-                        "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
-        out = {"metric": "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU", "value": q_total * args.steps / elapsed,
-               "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "gates_per_s": float(inst.n) * world * args.steps / elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
-               "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
-                                      % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
-                          "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)"},
-               "roofline": roofline, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
-               "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}}
-        if kernels is not None:
-            out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])}
-        if world == 1 and args.in_flight > 1:
-            try:
-                out["in_flight"] = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, local_rank, args.in_flight, max(2, args.steps))
-            except Exception as e:      # noqa: BLE001 - a failed secondary measurement must not lose the headline
-                out["in_flight"] = {"error": repr(e)}
-        if world == 1 and not args.headline_only and args.leaves == 512:
-            try:
-                out["end_to_end"] = end_to_end(bpg, workloads, ctx, a.gens_capacity, last[0] if rank == 0 else None, seed_for(args.steps - 1))
-            except Exception as e:      # noqa: BLE001
-                out["end_to_end"] = {"error": repr(e)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves)
-            out["cpu_baseline"]["host"] = "%d logical CPUs visible; 1 used" % (os.cpu_count() or 0)
-            if out["cpu_baseline"].get("value"):
-                # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
-                out["cpu_baseline"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-                out["cpu_baseline"]["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * out["cpu_baseline"]["value"])
-        print(json.dumps(out), flush=True)
+    # ---- roofline of the dominant kernel (HIP events on the engine's stream inside the timed steps) and of the whole proof
+    src = source_hash()
+    traffic_tab, traffic_note = {}, "no PMC profile stored"
+    tfile = ROOT / "profiles" / "pmc_traffic.json"
+    if tfile.exists():
+        try:
+            stored = json.loads(tfile.read_text())
+            if stored.get("_meta", {}).get("source_hash") == src:
+                traffic_tab = stored
+                traffic_note = "rocprofv3 --pmc passes of these sources (profiles/pmc_traffic.json: %s)" % stored["_meta"].get("note", "")
+            else:
+                traffic_note = "profiles/pmc_traffic.json was taken from other sources (hash %s, these are %s): not quoted" % (stored.get("_meta", {}).get("source_hash"), src)
+        except Exception as e:      # noqa: BLE001
+            traffic_note = "profiles/pmc_traffic.json unreadable: %r" % (e,)
+    peak_fm = ctx.bench_fe_mul(2000)
+    fold_group, tt_lg = int(os.environ.get("BPG_FOLD_GROUP", "3")), int(os.environ.get("BPG_TT_LG", "14"))
+    first_group = min(fold_group, max(a.gens_capacity.bit_length() - 1 - tt_lg, 0))
+    rocprof_name = {"k_fold_points_reg": "k_fold_points_reg<%d>" % ((1 << first_group) - 1)}
+
+    def kernel_roofline(name):
+        k = prof[name]
+        secs = k["total_ms"] * 1e-3
+        launches = max(k["count"], 1)
+        t = traffic_tab.get(rocprof_name.get(name, name))
+        return {"kernel": rocprof_name.get(name, name), "launches": k["count"], "avg_launch_ms": k["total_ms"] / launches,
+                "alg_bytes_per_launch": k["alg_bytes"] / launches, "achieved": k["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0,
+                "frac": k["alg_bytes"] / secs / 8e12 if secs > 0 else 0.0,
+                "traffic": t["hbm_bytes_per_launch"] if t else None,
+                "device_GBps": k["device_bytes"] / secs / 1e9 if secs > 0 else 0.0,
+                "valu": {"unit": "field-mult/s", "achieved": k["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
+                         "frac": (k["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
+                         "peak_source": "k_bench_fe_mul microbenchmark on this device"}}
+    ranked = sorted((n for n in prof if prof[n]["count"]), key=lambda n: -prof[n]["total_ms"])
+    # a tie (within 3 %) goes to the kernel with more launches, so that the line names the same kernel on every run
+    if len(ranked) > 1 and prof[ranked[1]]["total_ms"] > 0.97 * prof[ranked[0]]["total_ms"] and prof[ranked[1]]["count"] > prof[ranked[0]]["count"]:
+        ranked[0], ranked[1] = ranked[1], ranked[0]
+    b_alg = 576.0 * inst.n + 448.0 * a.gens_capacity           # algorithmic bytes of one proof
+    t_step = elapsed / args.steps
+    whole = {"alg_bytes": b_alg, "formula": "576 n + 448 N (SURVEY.md 8d)", "seconds": t_step, "achieved": b_alg / t_step / 1e9, "unit": "GB/s", "frac": b_alg / t_step / 8e12}
+    if ranked:
+        dom = kernel_roofline(ranked[0])
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
+                    "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_note, "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                    "alg_bytes_definition": "information content, SURVEY.md 8(d): S + P = 64 B per MSM term for the bucket sweep (once per term, not per window); "
+                                            "32 B per point read or written for a generator fold",
+                    "device_GBps": dom["device_GBps"],
+                    "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
+                            "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv)",
+                    "valu": dom["valu"], "whole_proof": whole, "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
+    else:
+        roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None, "whole_proof": whole,
+                    "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
+    fm_per_proof = sum(prof[n]["field_mults"] for n in prof) / max(args.steps, 1)
+
+    out = {"metric": METRIC, "value": q_total * args.steps / elapsed,
+           "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": t_step * 1e3, "gates_per_s": float(inst.n) * world * args.steps / elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
+           "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
+                                  % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
+                      "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
+                      "chain": ("the serial TranscriptRng chain of step i+1 is drawn by the context's chain worker (one host thread) while the kernels of step i run; "
+                                "all %d chains start and end inside the timed region" % args.steps) if prefetch else "every chain is drawn inside its own prove call",
+                      "backend": backend if world > 1 else None},
+           "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
+           "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
+           "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
+    if gpu_ms_per_proof is not None:
+        out["gpu_busy"] = {"kernel_ms_per_proof": gpu_ms_per_proof, "fraction_of_step": gpu_ms_per_proof / (t_step * 1e3),
+                           "note": "sum of the HIP-event durations of every kernel of one (untimed) proof / ms_per_step"}
+    if batch_info is not None:
+        out["batch"] = batch_info
+    if kernels is not None and args.kernel_profile:
+        out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])}
+    if world == 1 and args.in_flight > 1 and not args.headline_only:
+        try:
+            thr = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, args.in_flight, max(2, min(args.steps, 8)))
+            thr["note"] = ("independent proofs in flight on ONE GPU, one engine context and host thread each: the chains of the proofs run on %d host cores and the "
+                           "GPU is the bound; not the headline" % args.in_flight)
+            if gpu_ms_per_proof:
+                thr["kernel_ms_per_proof_alone"] = gpu_ms_per_proof
+                thr["gpu_time_fraction"] = gpu_ms_per_proof / thr["ms_per_proof"]
+            thr["valu"] = {"unit": "field-mult/s", "achieved": fm_per_proof * 1e3 / thr["ms_per_proof"], "peak": peak_fm,
+                           "frac": fm_per_proof * 1e3 / thr["ms_per_proof"] / peak_fm if peak_fm else None,
+                           "counted": "field multiplications of the bucket sweeps and the generator folds only (%.3g per proof)" % fm_per_proof}
+            thr["hbm"] = {"achieved": b_alg * 1e3 / thr["ms_per_proof"] / 1e9, "unit": "GB/s", "frac": b_alg * 1e3 / thr["ms_per_proof"] / 8e12}
+            out["throughput"] = thr
+        except Exception as e:      # noqa: BLE001 - a failed secondary measurement must not lose the headline
+            out["throughput"] = {"error": repr(e)}
+    if world == 1 and not args.headline_only and args.leaves == 512:
+        try:
+            out["end_to_end"] = end_to_end(bpg, workloads, ctx, a.gens_capacity, last[0], seed_for(args.steps - 1))
+        except Exception as e:      # noqa: BLE001
+            out["end_to_end"] = {"error": repr(e)}
+    if world == 1 and not args.no_cpu_baseline and not args.headline_only:
+        log("cpu_baseline: oracle on %d leaves (about %d s on one core) ..." % (args.baseline_leaves, 150 * args.baseline_leaves // 512 + 2))
+        cb = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves, {"leaves": args.leaves, "a": a, "inst": inst, "res": res})
+        cb["host"] = "%s, %d logical CPUs visible; 1 used" % (out["host"]["cpu_model"], os.cpu_count() or 0)
+        # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
+        cb["gpu_over_cpu"] = out["value"] / cb["value"]
+        cb["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * cb["value"])
+        out["cpu_baseline"] = cb
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline, args.in_flight = True, 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

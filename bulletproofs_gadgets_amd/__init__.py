@@ -84,6 +84,24 @@ def _buf(n):
     return C.create_string_buffer(max(n, 1))
 
 
+def _seed32(seed):
+    """The 32 bytes that stand in for upstream's thread_rng() draw: fresh OS randomness unless the caller pins them (tests, benchmarks).
+    A constant seed makes every blinding factor a function of the public transcript and the commitment blindings alone."""
+    if seed is None:
+        return os.urandom(32)
+    seed = bytes(seed)
+    if len(seed) != 32:
+        raise ValueError("rng seed must be exactly 32 bytes")
+    return seed
+
+
+def _exact(name, data, nbytes):
+    data = bytes(data)
+    if len(data) != nbytes:
+        raise ValueError("%s must be exactly %d bytes, got %d" % (name, nbytes, len(data)))
+    return data
+
+
 # ------------------------------------------------------------------------------------------------ scalars / conversions
 def scalar_from_int(x):
     return (x % L).to_bytes(32, "little")
@@ -240,7 +258,7 @@ class Context:
         _chk(lib().bpg_bench_fe_mul(self._h, C.c_uint32(iters), C.byref(r)))
         return r.value
 
-    def verify_flat(self, inst: "FlatInstance", transcript_state, commitments, proof, seed=bytes(32), flags=0):
+    def verify_flat(self, inst: "FlatInstance", transcript_state, commitments, proof, seed=None, flags=0):
         """bpg_r1cs_verify: 0 = accepted, 3 = VERIFICATION_ERROR, 2 = FORMAT_ERROR, 1 = INVALID_GENERATORS_LENGTH."""
         return _verify_flat(self, inst, transcript_state, commitments, proof, seed, flags)
 
@@ -253,11 +271,20 @@ class Context:
 
     def blinding_begin(self, transcript_state, v_blinding, rng_seed, max_multipliers):
         """bpg_blinding_begin: start the blinding chain of the next prove on this context (state after every "V" append, m x 32 blinding bytes)."""
-        ts = _buf(203); ts.raw = bytes(transcript_state)
-        _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, rng_seed, C.c_uint64(max_multipliers)))
+        ts = _buf(203); ts.raw = _exact("transcript_state", transcript_state, 203)
+        v_blinding = bytes(v_blinding)
+        if len(v_blinding) % 32:
+            raise ValueError("v_blinding must be a multiple of 32 bytes")
+        _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, _seed32(rng_seed), C.c_uint64(max_multipliers)))
 
-    def prove_flat(self, inst: "FlatInstance", transcript_state, v_blinding, rng_seed, flags=0):
-        ts = _buf(203); ts.raw = bytes(transcript_state)
+    def chain_cpu(self):
+        """Host core the chain worker of this context last drew a blinding stream on (-1: none yet)."""
+        lib().bpg_chain_cpu.restype = C.c_int32
+        return int(lib().bpg_chain_cpu(self._h))
+
+    def prove_flat(self, inst: "FlatInstance", transcript_state, v_blinding, rng_seed=None, flags=0):
+        ts = _buf(203); ts.raw = _exact("transcript_state", transcript_state, 203)
+        v_blinding, rng_seed = _exact("v_blinding", v_blinding, 32 * inst.m), _seed32(rng_seed)
         cap = lib().bpg_proof_size(inst.n, flags)
         out = _buf(cap); ln = C.c_uint64(cap)
         cs = inst.cstruct()
@@ -265,8 +292,9 @@ class Context:
         return out.raw[:ln.value], ts.raw[:203]
 
 
-def _verify_flat(ctx, inst, transcript_state, commitments, proof, seed=bytes(32), flags=0):
-    ts = _buf(203); ts.raw = bytes(transcript_state)
+def _verify_flat(ctx, inst, transcript_state, commitments, proof, seed=None, flags=0):
+    ts = _buf(203); ts.raw = _exact("transcript_state", transcript_state, 203)
+    seed, commitments, proof = _seed32(seed), _exact("commitments", commitments, 32 * inst.m), bytes(proof)
     cs = inst.cstruct()
     cs.aL = cs.aR = cs.aO = None
     return lib().bpg_r1cs_verify(ctx._h, C.byref(cs), ts, C.c_uint64(inst.m), commitments, proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags))
@@ -317,8 +345,9 @@ class ResidentCircuit:
     def __init__(self, ctx, h, n, m):
         self.ctx, self._h, self.n, self.m = ctx, h, n, m
 
-    def prove(self, transcript_state, v_blinding, rng_seed, flags=0, timings=False):
-        ts = _buf(203); ts.raw = bytes(transcript_state)
+    def prove(self, transcript_state, v_blinding, rng_seed=None, flags=0, timings=False):
+        ts = _buf(203); ts.raw = _exact("transcript_state", transcript_state, 203)
+        v_blinding, rng_seed = _exact("v_blinding", v_blinding, 32 * self.m), _seed32(rng_seed)
         cap = lib().bpg_proof_size(self.n, flags)
         out = _buf(cap); ln = C.c_uint64(cap)
         tm = Timings()
@@ -326,9 +355,10 @@ class ResidentCircuit:
                                            out, C.byref(ln), C.byref(tm) if timings else None))
         return (out.raw[:ln.value], ts.raw[:203], tm.as_dict()) if timings else (out.raw[:ln.value], ts.raw[:203])
 
-    def verify(self, transcript_state, commitments, proof, seed=bytes(32), flags=0):
+    def verify(self, transcript_state, commitments, proof, seed=None, flags=0):
         """bpg_r1cs_verify_resident: 0 = accepted, 3 = VERIFICATION_ERROR, 2 = FORMAT_ERROR, 1 = INVALID_GENERATORS_LENGTH."""
-        ts = _buf(203); ts.raw = bytes(transcript_state)
+        ts = _buf(203); ts.raw = _exact("transcript_state", transcript_state, 203)
+        seed, commitments, proof = _seed32(seed), _exact("commitments", commitments, 32 * self.m), bytes(proof)
         return lib().bpg_r1cs_verify_resident(self.ctx._h, self._h, ts, C.c_uint64(self.m), commitments, proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags))
 
     def free(self):
@@ -454,13 +484,18 @@ class Prover:
         m = view.m
         return FlatInstance(view, v=C.string_at(v, 32 * m) if m else b"", v_blinding=C.string_at(vb, 32 * m) if m else b"")
 
-    def start_blinding(self, rng_seed: bytes = bytes(32), max_multipliers: int = 1 << 20):
+    def start_blinding(self, rng_seed: bytes = None, max_multipliers: int = 1 << 20):
         """Extension (include/bpg.h bpg_prover_start_blinding): all commitments made - start the serial TranscriptRng chain of the coming
         prove(rng_seed) on a host thread while the constraints are still being assembled. The proof bytes do not change."""
-        _chk(lib().bpg_prover_start_blinding(self._h, rng_seed, C.c_uint64(max_multipliers)))
+        self._stream_seed = _seed32(rng_seed)      # prove() without an explicit seed continues with this one
+        _chk(lib().bpg_prover_start_blinding(self._h, self._stream_seed, C.c_uint64(max_multipliers)))
 
-    def prove(self, bp_gens, rng_seed: bytes = bytes(32), flags: int = 0):
-        """Prover::prove(&bp_gens) -> R1CSProof::to_bytes(); rng_seed stands in for thread_rng()."""
+    def prove(self, bp_gens, rng_seed: bytes = None, flags: int = 0):
+        """Prover::prove(&bp_gens) -> R1CSProof::to_bytes(); rng_seed stands in for thread_rng(): 32 fresh random bytes unless given
+        (a pinned seed is for tests and benchmarks only)."""
+        if rng_seed is None and getattr(self, "_stream_seed", None) is not None:
+            rng_seed = self._stream_seed
+        rng_seed = _seed32(rng_seed)
         capacity = bp_gens.gens_capacity if isinstance(bp_gens, BulletproofGens) else int(bp_gens)
         cap = lib().bpg_proof_size(self.get_num_multiplications(), flags)
         out = _buf(cap); ln = C.c_uint64(cap)
@@ -488,12 +523,13 @@ class Verifier:
 
     def get_num_vars(self): return lib().bpg_verifier_num_vars(self._h)
 
-    def verify(self, proof: bytes, ctx: "Context", bp_gens, seed: bytes = bytes(32), flags: int = 0):
+    def verify(self, proof: bytes, ctx: "Context", bp_gens, seed: bytes = None, flags: int = 0):
         """Verifier::verify(&proof, &pc_gens, &bp_gens) on the GPU: returns None, raises BpgError(VERIFICATION_ERROR / FORMAT_ERROR ...)."""
         capacity = bp_gens.gens_capacity if isinstance(bp_gens, BulletproofGens) else int(bp_gens)
+        seed, proof = _seed32(seed), bytes(proof)
         _chk(lib().bpg_verifier_verify(self._h, ctx._h, C.c_uint64(capacity), proof, C.c_uint64(len(proof)), seed, C.c_uint32(flags)))
 
-    def is_valid(self, proof, ctx, bp_gens, seed=bytes(32), flags=0):
+    def is_valid(self, proof, ctx, bp_gens, seed=None, flags=0):
         try:
             self.verify(proof, ctx, bp_gens, seed, flags)
             return True

@@ -101,7 +101,10 @@ template <class F> static bpg_status guard(F &&f) {
 static LinearCombination lc_from(const bpg_lc *lc) {
     REQUIRE(lc && (lc->n == 0 || lc->terms));
     LinearCombination out;
-    for (uint64_t i = 0; i < lc->n; i++) out.terms.emplace_back(Variable::unpack(lc->terms[i].var), Scalar::from_bits(lc->terms[i].coeff));
+    for (uint64_t i = 0; i < lc->n; i++) {
+        if ((lc->terms[i].var >> 29) > BPG_VAR_ONE) throw std::invalid_argument("linear combination holds an unknown variable kind");
+        out.terms.emplace_back(Variable::unpack(lc->terms[i].var), Scalar::from_bits(lc->terms[i].coeff));
+    }
     return out;
 }
 static void view(const FlatCircuit &f, bpg_r1cs_instance *o) {
@@ -369,6 +372,8 @@ bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[203],
         ctx->engine->blinding_begin(Transcript::from_state(transcript_state), vb, seed, max_multipliers);
     });
 }
+
+int32_t bpg_chain_cpu(bpg_ctx *ctx) { return ctx ? ctx->engine->chain_cpu() : -1; }
 
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t seed[32], uint32_t flags, uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings) {
     return guard([&] {

@@ -9,9 +9,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <sched.h>
 #include "engine.hpp"
 #include "hip/kernels.cuh"
 
@@ -158,25 +161,69 @@ struct Engine::Impl {
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
     PinBuf h_raw, h_small;
-    // Speculative blinding stream (Engine::blinding_begin): the leading draws of Prover::prove's TranscriptRng, produced on a host thread
-    // before the circuit is known.  snaps[k] = generator state before draw k * SNAP (after the three leading blinding scalars).
+    // Speculative blinding streams (Engine::blinding_begin): the leading draws of Prover::prove's TranscriptRng, produced on the context's
+    // chain worker (ONE host thread, FIFO) before the circuit is known - or, for a sequence of proofs, while the previous proof's kernels run.
+    // snaps[k] = generator state before draw k * SNAP (after the three leading blinding scalars).  Up to two streams are alive per context
+    // (the one being consumed and the next), each with its own pinned slab.
     struct BlindStream {
         static constexpr uint64_t SNAP = 4096;
-        std::thread th;
         std::atomic<uint64_t> produced{0};
-        std::atomic<bool> stop{false};
+        std::atomic<bool> stop{false}, finished{false};
+        std::atomic<int> cpu{-1};
         uint8_t state[203]; uint8_t seed[32]; std::vector<Scalar> vb;
         Scalar first[3];
         std::vector<TranscriptRng> snaps;
         uint64_t max_draws = 0;
+        int slot = 0; uint8_t *raw = nullptr;
     };
-    std::unique_ptr<BlindStream> blind;
-    PinBuf h_blind;
+    struct ChainWorker {
+        std::thread th; std::mutex mu; std::condition_variable cv;
+        std::deque<std::shared_ptr<BlindStream>> pending; bool quit = false;
+        static void run(ChainWorker *w) {
+            for (;;) {
+                std::shared_ptr<BlindStream> b;
+                { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
+                b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
+                TranscriptRng rng = b->snaps[0];
+                uint64_t pos = 0;
+                for (;;) {
+                    if (pos) b->snaps[pos / BlindStream::SNAP] = rng;                       // state before draw pos (snaps[0] was set by the caller)
+                    b->produced.store(pos, std::memory_order_release);                  // draws [0, pos) and snapshots up to pos are published
+                    if (pos >= b->max_draws || b->stop.load(std::memory_order_relaxed)) break;
+                    rng.fill_draws64(b->raw + 64 * pos, BlindStream::SNAP);
+                    pos += BlindStream::SNAP;
+                }
+                b->finished.store(true, std::memory_order_release);
+            }
+        }
+    };
+    std::unique_ptr<ChainWorker> chain;
+    std::deque<std::shared_ptr<BlindStream>> blinds;        // alive streams, oldest first (at most 2)
+    std::shared_ptr<BlindStream> slab_owner[2];             // last stream that wrote each pinned slab
+    PinBuf h_blind[2];
+    int last_chain_cpu = -1;
+    static void blind_stop(const std::shared_ptr<BlindStream> &b) {       // returns once the worker no longer touches b's slab
+        b->stop.store(true, std::memory_order_relaxed);
+    }
+    void blind_retire(const std::shared_ptr<BlindStream> &b) {
+        blind_stop(b);
+        if (chain) {   // still queued (never started)?  take it out; else wait for the worker to leave it
+            std::unique_lock<std::mutex> lk(chain->mu);
+            for (auto it = chain->pending.begin(); it != chain->pending.end(); ++it) if (it->get() == b.get()) { chain->pending.erase(it); b->finished.store(true); break; }
+        }
+        while (!b->finished.load(std::memory_order_acquire)) std::this_thread::yield();
+        const int c = b->cpu.load(std::memory_order_relaxed); if (c >= 0) last_chain_cpu = c;
+    }
     void blind_cancel() {
-        if (!blind) return;
-        blind->stop.store(true);
-        if (blind->th.joinable()) blind->th.join();
-        blind.reset();
+        while (!blinds.empty()) { blind_retire(blinds.front()); blinds.pop_front(); }
+    }
+    void chain_shutdown() {
+        blind_cancel();
+        if (!chain) return;
+        { std::lock_guard<std::mutex> lk(chain->mu); chain->quit = true; }
+        chain->cv.notify_all();
+        if (chain->th.joinable()) chain->th.join();
+        chain.reset();
     }
     uint64_t gens_cap = 0;
 
@@ -238,7 +285,7 @@ Engine::Engine(int device) : device_(device) {
 
 Engine::~Engine() {
     if (!impl_) return;
-    impl_->blind_cancel();
+    impl_->chain_shutdown();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(impl_->st);
     DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
@@ -247,7 +294,7 @@ Engine::~Engine() {
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
                       &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key};
     for (DevBuf *b : bufs) b->release();
-    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind.release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind[0].release(); impl_->h_blind[1].release();
     for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
@@ -454,9 +501,11 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
         BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>(),
                    buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH);
-        // roofline bookkeeping: one mixed addition (7 field multiplications) per entry; an entry is a 4-byte index and a point (32 B of
-        // information, 96 B in the device format).  Mub counts zero digits too (probability 2^-c each for full-width scalars).
-        prof_note(KID_k_bucket_chunks, 36.0 * (double)Mub, 100.0 * (double)Mub, 7.0 * (double)Mub);
+        // roofline bookkeeping.  Algorithmic bytes: the information content of the MSM this launch sweeps, one scalar + one
+        // point = 64 B per TERM, counted once however many windows the term is cut into.  Device bytes: every (term, window) entry is a
+        // 4-byte index and a 96-byte affine Niels point.  Work: one mixed addition (7 field multiplications) per entry; Mub counts zero
+        // digits too (probability 2^-c each for full-width scalars).
+        prof_note(KID_k_bucket_chunks, 64.0 * (double)total, 100.0 * (double)Mub, 7.0 * (double)Mub);
         BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH, heavy.as<uint32_t>());
         BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, lgCH, heavy.as<uint32_t>());
     }
@@ -784,10 +833,10 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
 void Engine::blinding_begin(const Transcript &after_commitments, const std::vector<Scalar> &v_blinding, const uint8_t seed[32], uint64_t max_multipliers) {
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
-    I.blind_cancel();
-    if (max_multipliers == 0) return;
+    if (max_multipliers == 0) { I.blind_cancel(); return; }
     using BS = Impl::BlindStream;
-    auto b = std::make_unique<BS>();
+    while (I.blinds.size() >= 2) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // two alive streams at most: the oldest gives way
+    auto b = std::make_shared<BS>();
     Transcript T = after_commitments;
     T.append_u64("m", v_blinding.size());
     T.export_state(b->state);
@@ -795,22 +844,20 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     TranscriptRng rng = T.build_rng(v_blinding, seed);
     for (int k = 0; k < 3; k++) b->first[k] = rng.random_scalar();
     b->max_draws = ((2 * max_multipliers + BS::SNAP - 1) / BS::SNAP) * BS::SNAP;
-    I.h_blind.ensure(b->max_draws * 64);
+    // pinned slab: the one no alive stream owns; its previous owner must have left it (its uploads were synchronised by the prove() that used it)
+    b->slot = (!I.blinds.empty() && I.blinds.front()->slot == 0) ? 1 : 0;
+    if (I.slab_owner[b->slot]) { I.blind_retire(I.slab_owner[b->slot]); I.slab_owner[b->slot].reset(); }
+    I.h_blind[b->slot].ensure(b->max_draws * 64);
+    b->raw = I.h_blind[b->slot].as<uint8_t>();
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
-    BS *p = b.get(); uint8_t *raw = I.h_blind.as<uint8_t>();
-    b->th = std::thread([p, raw, rng]() mutable {
-        uint64_t pos = 0;
-        for (;;) {
-            p->snaps[pos / BS::SNAP] = rng;                                  // state before draw pos
-            p->produced.store(pos, std::memory_order_release);               // draws [0, pos) and snapshots up to pos are published
-            if (pos >= p->max_draws || p->stop.load(std::memory_order_relaxed)) break;
-            rng.fill_draws64(raw + 64 * pos, BS::SNAP);
-            pos += BS::SNAP;
-        }
-    });
-    I.blind = std::move(b);
+    I.slab_owner[b->slot] = b;
+    I.blinds.push_back(b);
+    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); (void)keccak_impl(); I.chain->th = std::thread(Impl::ChainWorker::run, I.chain.get()); }
+    { std::lock_guard<std::mutex> lk(I.chain->mu); I.chain->pending.push_back(b); }
+    I.chain->cv.notify_one();
 }
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
+int Engine::chain_cpu() const { return impl_->last_chain_cpu; }
 
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
                                    const uint8_t rng_seed[32], uint32_t flags, ProveTimings *tm) {
@@ -835,15 +882,19 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     T.append_u64("m", m);
     const bool expanded = (flags & 4u) != 0;          // BPG_FLAG_EXPANDED_BLINDING: no host chain to hide behind
     // a speculative blinding stream is used only when it was drawn from exactly this transcript state, these blindings and this seed
-    Impl::BlindStream *bs = nullptr;
-    if (I.blind) {
+    std::shared_ptr<Impl::BlindStream> bs;
+    if (!I.blinds.empty()) {
         uint8_t now[203]; T.export_state(now);
-        const Impl::BlindStream &b = *I.blind;
-        bool ok = !expanded && 2 * n <= b.max_draws && std::memcmp(now, b.state, 203) == 0 && std::memcmp(rng_seed, b.seed, 32) == 0 && b.vb.size() == v_blinding.size();
-        for (size_t i = 0; ok && i < b.vb.size(); i++) ok = std::memcmp(b.vb[i].as_bytes(), v_blinding[i].as_bytes(), 32) == 0;
-        if (ok) bs = I.blind.get(); else I.blind_cancel();
+        for (const std::shared_ptr<Impl::BlindStream> &cand : I.blinds) {
+            const Impl::BlindStream &b = *cand;
+            bool ok = !expanded && 2 * n <= b.max_draws && std::memcmp(now, b.state, 203) == 0 && std::memcmp(rng_seed, b.seed, 32) == 0 && b.vb.size() == v_blinding.size();
+            for (size_t i = 0; ok && i < b.vb.size(); i++) ok = std::memcmp(b.vb[i].as_bytes(), v_blinding[i].as_bytes(), 32) == 0;
+            if (ok) { bs = cand; break; }
+        }
+        // no match: the alive streams may belong to later proofs of a sequence; they are bounded (two) and replaced by the next begin
     }
-    TranscriptRng rng = bs ? bs->snaps[0] : T.build_rng(v_blinding, rng_seed);
+    // (first[] and snaps[0] were written by blinding_begin on this thread, before the worker saw the stream)
+    TranscriptRng rng = T.build_rng(v_blinding, rng_seed);     // with a stream: replaced by the stream's generator once the 2n draws are in
     Scalar ib, ob, sb;
     if (bs) { ib = bs->first[0]; ob = bs->first[1]; sb = bs->first[2]; }
     else { ib = rng.random_scalar(); ob = rng.random_scalar(); sb = rng.random_scalar(); }
@@ -904,11 +955,11 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     } else
     {   // s_L[0..n) then s_R[0..n): 64 uniform bytes each, drawn in slabs; each slab is uploaded and reduced mod l while the
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
-        uint8_t *raw = bs ? I.h_blind.as<uint8_t>() : I.h_raw.as<uint8_t>();
+        uint8_t *raw = bs ? bs->raw : I.h_raw.as<uint8_t>();
         const uint64_t slab = 1u << 16;
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
-            if (bs) { while (bs->produced.load(std::memory_order_acquire) < i + cnt) std::this_thread::yield(); }     // drawn (or being drawn) by the stream thread
+            if (bs) { while (bs->produced.load(std::memory_order_acquire) < i + cnt) std::this_thread::sleep_for(std::chrono::microseconds(40)); }     // drawn (or being drawn) by the chain worker
             else rng.fill_draws64(raw + 64 * i, cnt);
             HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
             BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
@@ -917,10 +968,15 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     }
     if (bs) {   // take the generator back: the state before draw 2n is the last snapshot at or below it, advanced by the remainder
         const uint64_t K = (2 * n) / Impl::BlindStream::SNAP, rem = 2 * n - K * Impl::BlindStream::SNAP;
-        while (bs->produced.load(std::memory_order_acquire) < K * Impl::BlindStream::SNAP) std::this_thread::yield();
+        while (bs->produced.load(std::memory_order_acquire) < K * Impl::BlindStream::SNAP) std::this_thread::sleep_for(std::chrono::microseconds(20));
         rng = bs->snaps[K];
         if (rem) { std::vector<uint8_t> skip(rem * 64); rng.fill_draws64(skip.data(), rem); }
-        I.blind_cancel(); bs = nullptr;                    // stops the thread; its pinned buffer stays allocated, the queued uploads still read it
+        // done with the stream: the worker stops at its next snapshot and moves on to the next queued one; the pinned slab stays allocated
+        // (the queued uploads still read it) and is not handed out again before this prove() has synchronised the stream
+        Impl::blind_stop(bs);
+        for (auto it = I.blinds.begin(); it != I.blinds.end(); ++it) if (it->get() == bs.get()) { I.blinds.erase(it); break; }
+        { const int c = bs->cpu.load(std::memory_order_relaxed); if (c >= 0) I.last_chain_cpu = c; }
+        bs.reset();
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);

@@ -47,6 +47,7 @@ public:
     // transcript after the last commitment, v_blinding and the seed only.  prove() uses the stream iff all three still match, else discards it.
     void blinding_begin(const Transcript &after_commitments, const std::vector<Scalar> &v_blinding, const uint8_t seed[32], uint64_t max_multipliers);
     void blinding_cancel();
+    int chain_cpu() const;      // host core the chain worker last drew a stream on (-1: none yet); diagnostics for bench.py
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
     // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.
     R1CSError verify(DeviceCircuit *c, Transcript &transcript, const uint8_t *V, const uint8_t *proof, size_t proof_len,

@@ -133,6 +133,7 @@ public:
     MimcHash256() : image_(LinearCombination(Scalar::zero())) {}                                   // init()   :58-63
     explicit MimcHash256(const LinearCombination &image) : image_(image) {}                        // new()    :65-70
     std::vector<Scalar> preprocess(const std::vector<Scalar> &w) const override {                  // :15-37
+        if (w.empty()) throw R1CSException(R1CSError::GadgetError, "MimcHash256: empty witness");        // the reference indexes [len - 1] and panics
         Scalar padded;
         if (mimc_pad_last(w.back(), padded)) return {padded, padded - w.back()};
         return {padded};

@@ -211,12 +211,14 @@ public:
             if (t.first.kind == Variable::One) { acc += t.second; continue; }     // a constant term: c * 1 (round constants, keys) without the product
             const Scalar *x;
             static const Scalar ONE = Scalar::one();
+            // a stale or foreign variable (another prover's, a packed value from the C ABI) must not index past the vectors: dalek panics here
+            const size_t idx = t.first.idx;
             switch (t.first.kind) {
-            case Variable::MultiplierLeft: x = &aL_[t.first.idx]; break;
-            case Variable::MultiplierRight: x = &aR_[t.first.idx]; break;
-            case Variable::MultiplierOutput: x = &aO_[t.first.idx]; break;
-            case Variable::Committed: x = &v_[t.first.idx]; break;
-            default: x = &ONE; break;
+            case Variable::MultiplierLeft: if (idx >= aL_.size()) throw std::invalid_argument("linear combination refers to an unallocated multiplier"); x = &aL_[idx]; break;
+            case Variable::MultiplierRight: if (idx >= aR_.size()) throw std::invalid_argument("linear combination refers to an unallocated multiplier"); x = &aR_[idx]; break;
+            case Variable::MultiplierOutput: if (idx >= aO_.size()) throw std::invalid_argument("linear combination refers to an unallocated multiplier"); x = &aO_[idx]; break;
+            case Variable::Committed: if (idx >= v_.size()) throw std::invalid_argument("linear combination refers to an uncommitted variable"); x = &v_[idx]; break;
+            default: throw std::invalid_argument("linear combination holds an unknown variable kind");
             }
             static const Scalar MINUS_ONE = -Scalar::one();
             if (t.second == ONE) acc += *x;                          // most coefficients of the gadgets are +-1: skip the multiplication

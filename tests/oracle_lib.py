@@ -7,6 +7,7 @@ import subprocess
 
 ROOT = pathlib.Path(__file__).resolve().parent.parent
 LIB = ROOT / "oracle" / "build" / "liboracle.so"
+NATIVE_LIB = ROOT / "oracle" / "build" / "liboracle_native.so"
 
 FLAG_COMPACT_1PHASE = 1
 FLAG_NO_1PHASE_DOMSEP = 2
@@ -27,14 +28,33 @@ def build():
 
 
 _lib = None
+_lib_path = None
+
+
+def use_native():
+    """bench.py's cpu_baseline leg: build the oracle with -march=native ON THIS HOST and load that build (before any other use of the
+    oracle in the process). Returns the path loaded; falls back to the portable build when the native one cannot be made."""
+    global _lib_path
+    if _lib is not None:
+        return str(_lib_path)
+    try:
+        NATIVE_LIB.unlink(missing_ok=True)       # never trust a native build that travelled from another machine
+        subprocess.check_call(["make", "-C", str(ROOT / "oracle"), "native"], stdout=subprocess.DEVNULL)
+        _lib_path = NATIVE_LIB
+    except Exception:
+        _lib_path = None
+    lib()
+    return str(_lib_path)
 
 
 def lib():
-    global _lib
+    global _lib, _lib_path
     if _lib is None:
-        if not LIB.exists():
-            build()
-        _lib = C.CDLL(str(LIB))
+        if _lib_path is None:
+            if not LIB.exists():
+                build()
+            _lib_path = LIB
+        _lib = C.CDLL(str(_lib_path))
         _lib.orc_gens_new.restype = C.c_void_p
         _lib.orc_gens_new.argtypes = [C.c_uint64]
         _lib.orc_gens_from_compressed.restype = C.c_void_p

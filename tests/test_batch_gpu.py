@@ -1,0 +1,108 @@
+"""N > 1 path on the GPU (run with -m gpu): two fresh processes each own an engine context on cuda:0, prove their share of a batch of
+independent circuits with the PRODUCT (ResidentCircuit.prove, chains prefetched on the context's chain worker), all_gather the proof
+bytes (gloo: one GPU box has one card; the 8-GPU runs use the same code over RCCL) and every rank checks the whole batch with the GPU
+verifier and with the CPU oracle - bytes equal to the oracle prover's.  Also: bench.py --gpus 2 spawns its own ranks."""
+import json
+import os
+import pathlib
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import bulletproofs_gadgets_amd as bpg
+    from bulletproofs_gadgets_amd import workloads
+    from bulletproofs_gadgets_amd.batch import shard_indices, gather_proofs
+    import oracle_lib as O
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ctx = bpg.Context(0)                      # both ranks share the one card of the box
+    NUM = 5                                   # odd on purpose: ragged shards
+    def assembled(i):
+        # proof 0..3: 64-bit bounds checks with different witnesses, proof 4: a MiMC preimage (N = 1024, grouped-fold-free tail)
+        return workloads.mimc_preimage(ctx, nbytes=40, seed=i) if i == 4 else workloads.bounds_check_64(ctx, seed=i)
+    seed = lambda i: bytes([i + 1]) * 32
+    mine = shard_indices(NUM, rank, world)
+    items = []
+    for i in mine:
+        a = assembled(i)
+        inst = a.prover.instance()
+        ctx.gens_ensure(a.gens_capacity)
+        items.append((i, a, inst, ctx.upload(inst)))
+    local = {}
+    # chains prefetched one proof ahead on the context's chain worker (bpg_blinding_begin), exactly as bench.py sequences them
+    if items:
+        i, a, inst, res = items[0]
+        ctx.blinding_begin(a.transcript.state, inst.v_blinding, seed(i), inst.n)
+    for k, (i, a, inst, res) in enumerate(items):
+        if k + 1 < len(items):
+            j, a2, inst2, _ = items[k + 1]
+            ctx.blinding_begin(a2.transcript.state, inst2.v_blinding, seed(j), inst2.n)
+        proof, _ = res.prove(a.transcript.state, inst.v_blinding, seed(i), 0)
+        oc = O.FlatCircuit(inst.n, inst.m, inst.aL, inst.aR, inst.aO, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+        rc, want, _ = O.prove(O.Gens(a.gens_capacity), a.transcript.state, oc, inst.v_blinding, seed(i), O.FLAG_FAST_MSM)
+        assert rc == 0 and proof == want, "rank %%d proof %%d differs from the oracle" %% (rank, i)
+        local[i] = proof
+    sizes = {i: int(bpg.lib().bpg_proof_size(assembled(i).prover.get_num_multiplications(), 0)) for i in range(NUM)}
+    plen = max(sizes.values())
+    padded = {i: p + bytes(plen - len(p)) for i, p in local.items()}
+    proofs = gather_proofs(padded, NUM, plen, dist)
+    assert len(proofs) == NUM and all(p is not None for p in proofs)
+    # every rank rebuilds every statement on the verifier side and checks every proof on the GPU
+    for i in range(NUM):
+        a = assembled(i)
+        t = bpg.Transcript(a.transcript._label)
+        v = bpg.Verifier(t)
+        a.replay(v)
+        assert v.is_valid(proofs[i][:sizes[i]], ctx, a.gens_capacity), (rank, i)
+    a = assembled(0)
+    t = bpg.Transcript(a.transcript._label); v = bpg.Verifier(t); a.replay(v)
+    assert not v.is_valid(proofs[1][:sizes[1]], ctx, a.gens_capacity)          # a proof in the wrong slot must not verify
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.stdout.write("rank " + str(rank) + " ok\\n"); sys.stdout.flush()
+''') % (str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "golden"))
+
+
+def test_two_processes_one_gpu_gather_real_proofs(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
+
+
+def test_bench_spawns_its_own_ranks():
+    """python bench.py --gpus 2 without torchrun: the launcher starts two fresh ranks (gloo rehearsal on the one card) and relays ONE line."""
+    env = dict(os.environ, BPG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "8", "--batch", "4",
+                        "--no-cpu-baseline", "--in-flight", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert sorted(x["rank"] for x in out["ranks_seen"]) == [0, 1]
+    assert out["batch"]["proofs"] == 4 and out["batch"]["ranks"] == 2 and out["batch"]["proofs_per_rank"] == 2
+    assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0

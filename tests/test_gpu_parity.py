@@ -640,3 +640,42 @@ def test_speculative_blinding_stream_changes_no_byte(ctx):
         assert a == b == c
         rc, want, _ = O.prove(O.Gens(cap), state, to_oracle(inst), b"", seed, O.FLAG_FAST_MSM)
         assert rc == 0 and a == want
+
+
+def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
+    """The chain worker draws queued streams one at a time, in order; up to two stay alive (bench.py's sequence: begin(i+1), prove(i)).
+    Every proof of the sequence equals the stand-alone proof of the same seed; a third begin retires the oldest stream; proofs whose
+    stream was retired, never queued or queued out of order still come out byte-identical."""
+    a = workloads.mimc_preimage(ctx, nbytes=200, seed=3)               # n = 6,804: 2n crosses three snapshots of 4,096 draws
+    inst, state = a.prover.instance(), a.transcript.state
+    ctx.gens_ensure(a.gens_capacity)
+    res = ctx.upload(inst)
+    seeds = [bytes([k + 1]) * 32 for k in range(6)]
+    alone = [res.prove(state, inst.v_blinding, s, 0)[0] for s in seeds]
+    rc, want, _ = O.prove(O.Gens(a.gens_capacity), state, to_oracle(inst), inst.v_blinding, seeds[0], O.FLAG_FAST_MSM)
+    assert rc == 0 and alone[0] == want
+    assert len(set(alone)) == len(alone)
+    # the sequence of bench.py
+    ctx.blinding_begin(state, inst.v_blinding, seeds[0], inst.n)
+    got = []
+    for k, s in enumerate(seeds):
+        if k + 1 < len(seeds):
+            ctx.blinding_begin(state, inst.v_blinding, seeds[k + 1], inst.n)
+        got.append(res.prove(state, inst.v_blinding, s, 0)[0])
+    assert got == alone
+    assert ctx.chain_cpu() >= 0
+    # three begins in a row: the first stream gives way; proving in another order than queued, and a seed that was never queued
+    for s in seeds[:3]:
+        ctx.blinding_begin(state, inst.v_blinding, s, inst.n)
+    assert res.prove(state, inst.v_blinding, seeds[2], 0)[0] == alone[2]
+    assert res.prove(state, inst.v_blinding, seeds[0], 0)[0] == alone[0]      # retired: drawn inside prove
+    assert res.prove(state, inst.v_blinding, seeds[4], 0)[0] == alone[4]      # never queued
+    assert res.prove(state, inst.v_blinding, seeds[1], 0)[0] == alone[1]      # still alive, consumed now
+    # a stream sized for fewer multipliers than the circuit has is ignored; a context with queued streams can be torn down
+    ctx.blinding_begin(state, inst.v_blinding, seeds[5], 100)
+    assert res.prove(state, inst.v_blinding, seeds[5], 0)[0] == alone[5]
+    c2 = bpg.Context(0)
+    c2.blinding_begin(state, inst.v_blinding, seeds[0], 1 << 16)
+    c2.blinding_begin(state, inst.v_blinding, seeds[1], 1 << 16)
+    c2.close()
+    res.free()

@@ -2,6 +2,7 @@
 arithmetic, Merlin, MiMC, conversions and gadget assembly.  Circuits assembled by the product are handed to the
 ORACLE (tests/oracle_lib.py) for satisfaction / prove / verify checks."""
 import hashlib
+import pathlib
 import re
 import pytest
 import bulletproofs_gadgets_amd as bpg
@@ -240,3 +241,33 @@ def test_blinding_stream_needs_a_device_context():
     import ctypes as C
     rc = bpg.lib().bpg_blinding_begin(None, bytes(203), C.c_uint64(0), None, bytes(32), C.c_uint64(16))
     assert rc != 0 and b"" != bpg.lib().bpg_last_error()
+
+
+def test_bench_launcher_refuses_a_world_that_is_not_gpus(tmp_path):
+    """bench.py --gpus N is one rank of N under torchrun and the launcher of N ranks otherwise; a mismatch must fail loudly, not run 1 rank."""
+    import os, subprocess, sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+    # without a GPU the product refuses to run at all (no CPU path), also through the launcher
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "1"], env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs an AMD GPU" in r.stderr
+
+
+def test_python_binding_checks_buffer_lengths_and_defaults_to_fresh_seeds():
+    import bulletproofs_gadgets_amd as bpg
+    assert bpg._seed32(None) != bpg._seed32(None) and len(bpg._seed32(None)) == 32
+    assert bpg._seed32(bytes(32)) == bytes(32)
+    with pytest.raises(ValueError):
+        bpg._seed32(b"short")
+    with pytest.raises(ValueError):
+        bpg._exact("v_blinding", bytes(31), 32)
+    import inspect
+    for fn in (bpg.Prover.prove, bpg.Prover.start_blinding, bpg.Verifier.verify, bpg.Verifier.is_valid, bpg.ResidentCircuit.prove, bpg.ResidentCircuit.verify):
+        params = inspect.signature(fn).parameters
+        name = "rng_seed" if "rng_seed" in params else "seed"
+        assert params[name].default is None, fn.__qualname__

@@ -1,25 +1,46 @@
 #!/bin/bash
-# Evidence for profiles/: run on the GPU box from the repo root, e.g.  gpurun --timeout 1100 -- 'bash tools/profile_round.sh r01'
-#   1. the default bench line (with cpu_baseline and in_flight)                      -> gpurun_out/<tag>_bench_plain.json
-#   2. rocprofv3 --kernel-trace --stats of bench.py --headline-only and of plain bench.py -> gpurun_out/<tag>_stats/, <tag>_stats_default/  (+ bench lines under the profiler)
-#   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only           -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/
-# rocprofv3 gets the program itself after "--" (python3 bench.py ...), never a shell or env wrapper.
+# Evidence for profiles/: run on the GPU box from the repo root, e.g.
+#   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 calib stats pmc'      and      gpurun --timeout 900 -- 'bash tools/profile_round.sh r02 bench'
+# stages (any subset, in this order):
+#   calib  FETCH_SIZE calibration on a known byte count (tools/calib/gather_calib.hip)          -> gpurun_out/<tag>_fetch_calibration.json
+#   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only and --in-flight-only    -> gpurun_out/<tag>_stats/, <tag>_stats_inflight/ (+ the bench lines under the profiler)
+#   pmc    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only                -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/, <tag>_pmc_traffic.json
+#   bench  the default bench line exactly as the driver runs it (cpu_baseline, throughput, batch) -> gpurun_out/<tag>_bench_plain.json
+# rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}; shift
+stages=${*:-calib stats pmc bench}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
-timeout -k 10 400 python3 bench.py > "$out/${tag}_bench_plain.json" 2> "$out/${tag}_bench_plain.err" || { echo "bench failed"; tail -5 "$out/${tag}_bench_plain.err"; exit 1; }
-echo "bench done"
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err" || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
-echo "stats done"
-# the same, for the default command line exactly as the driver runs it (verify / expanded-blinding / in-flight / CPU-baseline legs included:
-# more launches of the same kernels, so only the fixed-size ones - the generator folds - keep the averages of the headline-only pass)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_default" -o "$tag" -- python3 "$root/bench.py" > "$out/${tag}_bench_default_under_rocprof.json" 2> "$out/${tag}_stats_default.err" || { echo "default-command stats pass failed"; tail -5 "$out/${tag}_stats_default.err"; exit 1; }
-echo "default-command stats done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err" || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
-echo "fetch done"
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err" || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
-echo "write done"
+export TMPDIR=/tmp
+has() { [[ " $stages " == *" $1 "* ]]; }
+csv() { find "$1" -name "*$2" | head -1; }
+
+if has calib; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/gather_calib "$root/tools/calib/gather_calib.hip" || { echo "calib build failed"; exit 1; }
+    (cd /tmp && timeout -k 10 120 /tmp/gather_calib > "$out/${tag}_calib_known.json") || { echo "calib run failed"; exit 1; }
+    (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_calib_pmc" -o "$tag" -- /tmp/gather_calib > /dev/null 2> "$out/${tag}_calib_pmc.err") || { echo "calib pmc pass failed"; tail -5 "$out/${tag}_calib_pmc.err"; exit 1; }
+    python3 "$root/tools/calib/fetch_factor.py" "$out/${tag}_calib_known.json" "$(csv "$out/${tag}_calib_pmc" counter_collection.csv)" "$out/${tag}_fetch_calibration.json" || exit 1
+    echo "calib done"
+fi
+if has stats; then
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 5 --warmup 2 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err") || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
+    echo "stats done"
+    # the concurrent mix of the throughput leg: 12 proofs in flight on 12 streams, kernels of different proofs share the CUs
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight 12 --steps 4 > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
+    echo "in-flight stats done"
+fi
+if has pmc; then
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err") || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
+    echo "fetch done"
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err") || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
+    echo "write done"
+    calib="$out/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/${tag}_fetch_calibration.json"
+    python3 "$root/tools/pmc_summarize.py" "$(csv "$out/${tag}_pmc_fetch" counter_collection.csv)" "$(csv "$out/${tag}_pmc_write" counter_collection.csv)" "$calib" "$out/${tag}_pmc_traffic.json" || exit 1
+fi
+if has bench; then
+    timeout -k 10 800 python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_plain.json" 2> "$out/${tag}_bench_plain.err" || { echo "bench failed"; tail -5 "$out/${tag}_bench_plain.err"; exit 1; }
+    echo "bench done"
+fi
 find "$out" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
