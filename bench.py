@@ -109,6 +109,14 @@ def pin_near_gpu(torch, device_index):
     return info
 
 
+def current_cpu():
+    try:
+        import ctypes
+        return int(ctypes.CDLL(None).sched_getcpu())
+    except Exception:       # noqa: BLE001
+        return None
+
+
 def host_description():
     model = None
     try:
@@ -355,7 +363,7 @@ def run_rank(args):
     q_total = allreduce(float(inst.q), dist.ReduceOp.SUM if dist else None)
     chain_cpu = ctx.chain_cpu()
     ranks_seen = gather_objects({"rank": rank, "device": device_index, "pci": placement.get("pci"), "numa_node": placement.get("numa_node"),
-                                 "cpus_allowed": placement.get("cpus_allowed"), "chain_cpu": chain_cpu, "main_cpu": os.sched_getcpu() if hasattr(os, "sched_getcpu") else None,
+                                 "cpus_allowed": placement.get("cpus_allowed"), "chain_cpu": chain_cpu, "main_cpu": current_cpu(),
                                  "ms_per_step": elapsed_local / args.steps * 1e3})
     last = outs[-1]
 

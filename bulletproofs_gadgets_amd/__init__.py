@@ -338,7 +338,10 @@ class ProverPool:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ResidentCircuit:
@@ -408,7 +411,8 @@ class Transcript:
 
     def __init__(self, label: bytes):
         self._h = C.c_void_p()
-        _chk(lib().bpg_transcript_new(bytes(label), C.c_uint64(len(label)), C.byref(self._h)))
+        self.label = bytes(label)           # a verifier rebuilds its transcript from the same label
+        _chk(lib().bpg_transcript_new(self.label, C.c_uint64(len(label)), C.byref(self._h)))
 
     def append_message(self, label: bytes, msg: bytes):
         _chk(lib().bpg_transcript_append_message(self._h, label, bytes(msg), C.c_uint64(len(msg))))
@@ -425,9 +429,12 @@ class Transcript:
         return out.raw[:203]
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().bpg_transcript_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().bpg_transcript_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the module globals may be gone
+            pass
 
 
 class Prover:
@@ -503,9 +510,12 @@ class Prover:
         return out.raw[:ln.value]
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().bpg_prover_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().bpg_prover_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the module globals may be gone
+            pass
 
 
 class Verifier:
@@ -544,9 +554,12 @@ class Verifier:
         return FlatInstance(view, commitments=C.string_at(coms, 32 * view.m) if view.m else b"")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().bpg_verifier_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().bpg_verifier_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the module globals may be gone
+            pass
 
 
 class ConstraintBuffer:
@@ -567,9 +580,12 @@ class ConstraintBuffer:
         return lib().bpg_buffer_next_multiplier(self._h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().bpg_buffer_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().bpg_buffer_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the module globals may be gone
+            pass
 
 
 def or_conjunction(main, buffer: ConstraintBuffer):
@@ -653,9 +669,12 @@ class Gadget:
         _chk(fn(self._h, verifier._h, v, C.c_uint64(len(witnesses)), dv, C.c_uint64(len(derived))))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().bpg_gadget_free(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().bpg_gadget_free(self._h)
+                self._h = None
+        except Exception:       # interpreter shutdown: the module globals may be gone
+            pass
 
 
 class BoundsCheck(Gadget):

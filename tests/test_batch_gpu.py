@@ -23,7 +23,11 @@ def _free_port():
 
 
 WORKER = textwrap.dedent('''
-    import os, sys
+    import os, sys, traceback
+    def _report(t, v, tb):
+        sys.stdout.write("WORKER FAILED: " + "".join(traceback.format_exception(t, v, tb))); sys.stdout.flush()
+        os._exit(1)
+    sys.excepthook = _report
     sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
     import torch, torch.distributed as dist
     import bulletproofs_gadgets_amd as bpg
@@ -67,12 +71,12 @@ WORKER = textwrap.dedent('''
     # every rank rebuilds every statement on the verifier side and checks every proof on the GPU
     for i in range(NUM):
         a = assembled(i)
-        t = bpg.Transcript(a.transcript._label)
+        t = bpg.Transcript(a.transcript.label)
         v = bpg.Verifier(t)
         a.replay(v)
         assert v.is_valid(proofs[i][:sizes[i]], ctx, a.gens_capacity), (rank, i)
     a = assembled(0)
-    t = bpg.Transcript(a.transcript._label); v = bpg.Verifier(t); a.replay(v)
+    t = bpg.Transcript(a.transcript.label); v = bpg.Verifier(t); a.replay(v)
     assert not v.is_valid(proofs[1][:sizes[1]], ctx, a.gens_capacity)          # a proof in the wrong slot must not verify
     dist.barrier()
     dist.destroy_process_group()
