@@ -246,6 +246,9 @@ def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
 
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
+    # the throughput leg runs a dozen engine streams: 8 hardware queues instead of the runtime's default 4 measured 8 % more proofs/s
+    # (tools/diag/exp1.sh); read by the HIP runtime at initialisation, so set before torch / the library load it
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

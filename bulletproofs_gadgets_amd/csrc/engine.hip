@@ -80,6 +80,28 @@ int32_t naf256(const Scalar &s, int8_t d[256]) {
     return top;
 }
 
+// width-w non-adjacent form of a canonical scalar: odd digits in (-2^(w-1), 2^(w-1)), at most one non-zero in any w consecutive positions;
+// returns the index of the top non-zero digit (-1 for zero).  Scalars are < 2^253, so position 255 is never reached.
+int32_t wnaf256(const Scalar &s, uint32_t w, int8_t d[256]) {
+    uint64_t k[5] = {s.w[0], s.w[1], s.w[2], s.w[3], 0};
+    std::memset(d, 0, 256);
+    int32_t top = -1;
+    const int64_t full = 1ll << w, half = 1ll << (w - 1);
+    for (int i = 0; i < 256; i++) {
+        if ((k[0] | k[1] | k[2] | k[3] | k[4]) == 0) break;
+        if (k[0] & 1) {
+            int64_t dig = (int64_t)(k[0] & (uint64_t)(full - 1));
+            if (dig >= half) dig -= full;
+            d[i] = (int8_t)dig; top = i;
+            if (dig > 0) { k[0] -= (uint64_t)dig; }                                                   // low bits cleared, no borrow
+            else { uint64_t add = (uint64_t)(-dig); for (int j = 0; j < 5; j++) { uint64_t t = k[j] + add; add = t < add ? 1 : 0; k[j] = t; if (!add) break; } }
+        }
+        for (int j = 0; j < 4; j++) k[j] = (k[j] >> 1) | (k[j + 1] << 63);
+        k[4] >>= 1;
+    }
+    return top;
+}
+
 uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; return l; }
 
 }  // namespace
@@ -94,7 +116,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_odd_start) X(k_odd_step) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
@@ -120,7 +142,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_bucket_chunks)); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_bucket_chunks)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -135,6 +157,7 @@ struct Engine::Impl {
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
     DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, chunk_key;
+    uint32_t tile_shift = 6, tile_lgmax = 14, tile_threads = 256;   // sort tiles: 2^-tile_shift of an MSM's terms, at most 2^tile_lgmax (BPG_TILE_SHIFT, BPG_TILE_LGMAX, BPG_TILE_THREADS)
     uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
@@ -156,6 +179,25 @@ struct Engine::Impl {
         if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
     }
     PinBuf h_naf;
+    // odd multiples 3P, 5P, .. (2^(w-1) - 1)P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf);
+    // built on first use for the current generator tables, rebuilt when those are extended
+    DevBuf gens_odd; uint32_t fold_wnaf = 6; uint32_t odd_w = 0; uint64_t odd_cap = 0; const void *odd_gens = nullptr;
+    void odd_ensure() {
+        if (odd_w == fold_wnaf && odd_cap == gens_cap && odd_gens == gens.p) return;
+        const uint32_t nm = (1u << (fold_wnaf - 2)) - 1u, cnt = (uint32_t)(2 * gens_cap);
+        gens_odd.ensure((size_t)nm * cnt * sizeof(ge_niels));
+        scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
+        DevBuf dbl; dbl.ensure((size_t)cnt * sizeof(ge_ext));
+        BPG_LAUNCH((*this), k_odd_start, dim3(cdiv(cnt, 256)), dim3(256), gens.as<ge_niels>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
+        for (uint32_t m = 1; m <= nm; m++) {
+            if (m > 1) BPG_LAUNCH((*this), k_odd_step, dim3(cdiv(cnt, 256)), dim3(256), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
+            BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), gens_odd.as<ge_niels>() + (size_t)(m - 1) * cnt, cnt);
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        dbl.release();
+        odd_w = fold_wnaf; odd_cap = gens_cap; odd_gens = gens.p;
+    }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -260,9 +302,13 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TILE_SHIFT")) { int v = std::atoi(e); if (v >= 0 && v <= 10) impl_->tile_shift = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 7)) impl_->fold_wnaf = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
@@ -292,7 +338,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->gens_odd};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind[0].release(); impl_->h_blind[1].release();
     for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
@@ -459,7 +505,7 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     MsmPlan P; std::memset(&P, 0, sizeof P);
     P.nmsm = nmsm; P.W = W; P.nb = nb;
     {
-        uint32_t lg = ceil_log2(per) > 6 ? ceil_log2(per) - 6 : 0; if (lg < 10) lg = 10; if (lg > 14) lg = 14;
+        uint32_t lg = ceil_log2(per) > tile_shift ? ceil_log2(per) - tile_shift : 0; if (lg < 10) lg = 10; if (lg > tile_lgmax) lg = tile_lgmax;
         P.lgTile = lg;
         uint32_t k = 0;
         for (uint32_t m = 0; m < nmsm; m++) {
@@ -489,12 +535,12 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     chunk_key.ensure((size_t)nchunks * 4); P.lgCH = lgCH;
     plain.ensure((size_t)(total ? total : 1) * 32);
     if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(256), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
     BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
     BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
     BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(256), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>());
+    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>());
     {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
@@ -766,6 +812,37 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 const Scalar &uk = g_us[k - 1]; const Scalar ukinv = uk.invert();
                 fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
             }
+            ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            const bool use_wnaf = I.fold_wnaf >= 3 && !I.fold_from_memory && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max;
+            if (use_wnaf) {
+                // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf)
+                I.odd_ensure();
+                const size_t dbytes = (size_t)4 * nterms * 256;
+                I.h_naf.ensure(dbytes); I.naf.ensure(dbytes);
+                int8_t *hd = I.h_naf.as<int8_t>();
+                std::memset(hd, 0, dbytes);
+                int32_t top = -1; double adds_fm = 0;
+                for (uint32_t q = 0; q < nterms; q++) {
+                    const uint32_t t = q + 1;
+                    Scalar sg = Scalar::one(), sh = Scalar::one();
+                    for (uint32_t k = 1; k <= g_r; k++) if ((t >> (g_r - k)) & 1u) { sg = sg * fG[k - 1]; sh = sh * fH[k - 1]; }
+                    const Scalar cls_s[4] = {sg, sg * u_ch, sh, sh * u_ch};
+                    const uint64_t lo = (uint64_t)t * Mr, nB = !g_first ? 0 : (lo >= n ? Mr : (lo + Mr > n ? lo + Mr - n : 0));
+                    for (int cls = 0; cls < 4; cls++) {
+                        if ((cls & 1) && !g_first) continue;
+                        int8_t *d = hd + ((size_t)cls * nterms + q) * 256;
+                        const int32_t tp = wnaf256(cls_s[cls], I.fold_wnaf, d);
+                        if (tp > top) top = tp;
+                        int adds = 0; for (int k = 0; k < 256; k++) adds += d[k] != 0;
+                        adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
+                    }
+                }
+                HIPCHK(hipMemcpyAsync(I.naf.p, hd, dbytes, hipMemcpyHostToDevice, st));
+                FoldWnaf fw; fw.Mr = Mr; fw.nterms = nterms; fw.first_group = g_first; fw.n = (uint32_t)n; fw.cap = (uint32_t)gens_cap; fw.top = top;
+                BPG_LAUNCH(I, k_fold_points_wnaf, dim3(cdiv(2 * Mr, 256)), dim3(256), I.gens.as<ge_niels>(), I.gens_odd.as<ge_niels>(), I.scratch_ext.as<ge_ext>(),
+                           I.naf.as<uint32_t>(), fw);
+                I.prof_note(KID_k_fold_points_wnaf, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * (2.0 * Mr + adds_fm / 7.0) + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);
+            } else {
             I.h_naf.ensure((size_t)4 * nterms * 16 * 4); I.naf.ensure((size_t)4 * nterms * 16 * 4);
             uint32_t *hn = I.h_naf.as<uint32_t>();
             std::memset(hn, 0, (size_t)4 * nterms * 16 * 4);
@@ -788,7 +865,6 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             }
             HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
             FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
-            ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
             int fold_kid = KID_k_fold_points;
             {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
@@ -809,6 +885,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             // field multiplications: 8 per doubling, 7 per mixed addition (the split variant runs the doublings once per wave of a block)
             I.prof_note(fold_kid, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * 2 * g_M + 128.0 * 2 * Mr,
                         2.0 * Mr * (8.0 * (top + 1) * (fold_kid == KID_k_fold_points_split ? (nterms < 4 ? nterms : 4) : 1) + 7.0) + adds_fm);
+            }
             BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
             HIPCHK(hipGetLastError());
             HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group
@@ -912,7 +989,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
     const bool tabled = I.tt_lg > 0 && N <= (1ull << I.tt_lg) && n > 0;   // the generators have (or get) window tables: A_I, A_O, S are table sums
     if (tabled) I.tt_build(Gtab, Htab, Bn, (uint32_t)N, true);
-    const bool merged = expanded || tabled || n < 4096;   // nothing worth hiding: A_I, A_O, S in one pass after the draws (one serial tail, not three)
+    // the stream of this proof was drawn ahead (a sequence of proofs: its chain ran under the previous proof's kernels) and is complete
+    const bool chain_ready = bs && bs->produced.load(std::memory_order_acquire) >= 2 * n;
+    const bool merged = expanded || tabled || n < 4096 || chain_ready;   // nothing to hide behind: A_I, A_O, S in one pass after the draws (one serial tail, not four)
     if (!merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);

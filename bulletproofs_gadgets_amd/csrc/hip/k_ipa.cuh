@@ -407,6 +407,73 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     if (live) out[t] = ge_madd(acc, tab[i]);
 }
 
+// Fold of a group whose tables are the ORIGINAL generators (the first group of every proof above the table tail): the generators never
+// change, so their odd multiples odd[m-1][p] = (2m+1) * P_p, m = 1 .. 2^(w-2) - 1, are built once per capacity (k_odd_start / k_odd_step,
+// affine Niels) and the shared scalars are recoded in width-w NAF: one addition per w+1 bits instead of one per 3 (36 instead of 84 per
+// term at w = 6), each addend read from memory when its digit comes up - lane i of a wave reads point i of the same table: coalesced, and
+// no addend lives in registers.  dig: [4 classes][nterms][256] signed odd digits (int8, 0 = none), class = 2*isH + isB as in k_fold_points.
+struct FoldWnaf { uint32_t Mr, nterms, first_group, n, cap; int32_t top; };
+__device__ __forceinline__ int32_t fold_wnaf_digit(const uint32_t *__restrict__ dig32, uint32_t cls, uint32_t nterms, uint32_t q, int k) {
+    const uint32_t w = dig32[(cls * nterms + q) * 64u + ((uint32_t)k >> 2)];
+    return (int32_t)(int8_t)(w >> (8u * ((uint32_t)k & 3u)));
+}
+__global__ void __launch_bounds__(256) k_fold_points_wnaf(const ge_niels *__restrict__ gens /* [G | H], 2*cap */, const ge_niels *__restrict__ odd /* [m-1][2*cap] */,
+                                                          ge_ext *__restrict__ out /* 2*Mr */, const uint32_t *__restrict__ dig32, const FoldWnaf fg) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < 2 * fg.Mr;
+    if (!live) t = 2 * fg.Mr - 1;                           // keep whole waves converged; the store is guarded
+    const bool isH = t >= fg.Mr;
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const uint32_t base = (isH ? fg.cap : 0u) + i;           // index of P_i in every multiple table
+    const size_t tab = (size_t)2 * fg.cap;
+    uint32_t bmask = 0;
+    if (fg.first_group) for (uint32_t q = 0; q < fg.nterms; q++) if (i + (q + 1) * fg.Mr >= fg.n) bmask |= 1u << q;
+    const uint32_t key = (isH ? 0x80000000u : 0u) | bmask;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    const uint32_t hsel = isH ? 2u : 0u;
+    ge_ext acc = ge_identity();
+    if (__ballot(key != key0) == 0ull) {                    // every lane agrees on the class of every term: scalar digit loads, scalar branches
+        const uint32_t hs = (key0 >> 31) * 2u;
+        for (int k = fg.top; k >= 0; k--) {
+            acc = ge_dbl(acc);
+            for (uint32_t q = 0; q < fg.nterms; q++) {
+                const int32_t d = __builtin_amdgcn_readfirstlane(fold_wnaf_digit(dig32, hs + ((key0 >> q) & 1u), fg.nterms, q, k));
+                if (d != 0) {
+                    const uint32_t mag = (uint32_t)(d < 0 ? -d : d), m = mag >> 1;
+                    const ge_niels *T = m ? odd + (size_t)(m - 1) * tab : gens;
+                    acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+                }
+            }
+        }
+    } else {
+        for (int k = fg.top; k >= 0; k--) {
+            acc = ge_dbl(acc);
+            for (uint32_t q = 0; q < fg.nterms; q++) {
+                const int32_t d = fold_wnaf_digit(dig32, hsel + ((bmask >> q) & 1u), fg.nterms, q, k);
+                if (d != 0) {
+                    const uint32_t mag = (uint32_t)(d < 0 ? -d : d), m = mag >> 1;
+                    const ge_niels *T = m ? odd + (size_t)(m - 1) * tab : gens;
+                    acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+                }
+            }
+        }
+    }
+    if (live) out[t] = ge_madd(acc, gens[base]);
+}
+// odd multiples of the generators: cur = P, dbl = 2P; each step cur += dbl gives the next odd multiple (normalised by k_normalize_niels)
+__global__ void __launch_bounds__(256) k_odd_start(const ge_niels *__restrict__ gens, ge_ext *__restrict__ cur, ge_ext *__restrict__ dbl, uint32_t count) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const ge_ext e = ge_madd(ge_identity(), gens[p]);
+    const ge_ext d = ge_dbl(e);
+    cur[p] = ge_add(e, d); dbl[p] = d;                       // 3P
+}
+__global__ void __launch_bounds__(256) k_odd_step(ge_ext *__restrict__ cur, const ge_ext *__restrict__ dbl, uint32_t count) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    cur[p] = ge_add(cur[p], dbl[p]);
+}
+
 // Latency variant of the same fold for small tables (2*Mr <= 64 K outputs: one wave per SIMD at most, so the kernel is one
 // dependent chain of 253 doublings + nterms * 84 additions whatever it does): the terms of an output are dealt to the FOUR
 // waves of a block (term q goes to wave q mod 4), each wave runs its own chain of doublings over its <= 4 addends with

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_
 // pass 1 also notes, for every chunk of 2^lgCH sorted entries, the key of the chunk's first entry (chunk_key): k_bucket_chunks starts
 // from it instead of searching starts[]
 template <int PASS>
-__global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
+__global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
                                                   const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
     extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
     const uint32_t T = blockIdx.x, win = blockIdx.y;
@@ -71,12 +71,12 @@ __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const ui
     const uint32_t g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
     const uint32_t mw = m * P.W + win;
     uint32_t *row = H + ((size_t)mw * P.tmax + t) * P.nb;
-    if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = 0;
-    else for (uint32_t b = threadIdx.x; b < P.nb; b += 256) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
+    if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) tile_lds[b] = 0;
+    else for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
     __syncthreads();
     // the window's bits sit in one or two of the eight words: read only the 16-byte half (or both halves) that holds them
     const uint32_t off = msm_off(win, P.W), wd = msm_off(win + 1, P.W) - off, wi = off >> 5, sh = off & 31;
-    for (uint32_t g = g0 + threadIdx.x; g < g1; g += 256) {
+    for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
         const uint32_t *pw = reinterpret_cast<const uint32_t *>(plain + 2 * (size_t)g);
         const uint64_t two = (uint64_t)pw[wi] | ((uint64_t)(wi + 1 < 8 ? pw[wi + 1] : 0u) << 32);
         const int32_t d = (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) k_msm_tile(MsmSegs S, MsmPlan P, const ui
     }
     if (PASS == 0) {
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < P.nb; b += 256) row[b] = tile_lds[b];
+        for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) row[b] = tile_lds[b];
     }
 }
 // one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
@@ -118,11 +118,20 @@ __global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restri
     for (uint32_t d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d]; __syncthreads(); }
     if (threadIdx.x == 0) blocksum[blockIdx.x] = lds[0];
 }
-__global__ void k_scan_top(uint32_t *__restrict__ blocksum, uint32_t nblocks) {   // single thread: nblocks <= a few thousand
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < nblocks; b++) { uint32_t v = blocksum[b]; blocksum[b] = run; run += v; }
-    blocksum[nblocks] = run;
+// exclusive scan of the block sums in place (blocksum[nblocks] = grand total): ONE wave; lane l owns the contiguous slice
+// [l*per, (l+1)*per), sums it, the 64 slice sums are scanned with shuffles, then each lane rewrites its slice
+__global__ void __launch_bounds__(64) k_scan_top(uint32_t *__restrict__ blocksum, uint32_t nblocks) {
+    if (blockIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x & 63u, per = (nblocks + 63u) / 64u;
+    const uint32_t b0 = min(lane * per, nblocks), b1 = min(b0 + per, nblocks);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += blocksum[b];
+    uint32_t incl = sum;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    uint32_t run = incl - sum;
+    for (uint32_t b = b0; b < b1; b++) { const uint32_t v = blocksum[b]; blocksum[b] = run; run += v; }
+    if (lane == 63) blocksum[nblocks] = incl;
 }
 __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ counts, uint32_t nkeys, const uint32_t *__restrict__ blocksum,
                                                     uint32_t *__restrict__ starts, uint32_t *__restrict__ cursor) {
@@ -266,12 +275,12 @@ __global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ 
 // four waves concurrently (each wave is on its own SIMD, its lanes all hold the same value) and exchanged through LDS.
 // A single lane needs ~2,600 instructions per doubling; here each wave issues ~1/4 of that between two barriers.
 struct HornerLds { fe c[4]; fe s[4]; };
-__device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv) {
+__device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv, bool lane0) {
     // L.c = (X, Y, Z, T) -> doubled point in L.c
     fe in = (wv == 3) ? fe_add(L.c[0], L.c[1]) : L.c[wv];          // X, Y, Z, X+Y
     fe sq = fe_sq(in);
     __syncthreads();
-    L.s[wv] = sq;                                                  // XX, YY, ZZ, (X+Y)^2
+    if (lane0) L.s[wv] = sq;                                       // XX, YY, ZZ, (X+Y)^2 (one lane stores: every lane holds the same value)
     __syncthreads();
     fe XX = L.s[0], YY = L.s[1];
     fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
@@ -285,10 +294,10 @@ __device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv) {
         else { a = cX; b = YpX; }                                   // T3 = cX * YpX
     }
     fe r = fe_mul(a, b);
-    L.c[wv] = r;
+    if (lane0) L.c[wv] = r;
     __syncthreads();
 }
-__device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32_t wv) {
+__device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32_t wv, bool lane0) {
     // L.c += q   (extended + extended, unified formulas)
     fe X1 = L.c[0], Y1 = L.c[1];
     fe p;
@@ -297,25 +306,26 @@ __device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32
     else if (wv == 2) p = fe_mul(fe_mul(L.c[3], q.T), FE_D2());     // C
     else { p = fe_mul(L.c[2], q.Z); p = fe_add(p, p); }             // D
     __syncthreads();
-    L.s[wv] = p;
+    if (lane0) L.s[wv] = p;
     __syncthreads();
     fe A = L.s[0], B = L.s[1], C = L.s[2], D = L.s[3];
     fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
     fe r = (wv == 0) ? fe_mul(E, F) : (wv == 1) ? fe_mul(G, H) : (wv == 2) ? fe_mul(F, G) : fe_mul(E, H);
-    L.c[wv] = r;
+    if (lane0) L.c[wv] = r;
     __syncthreads();
 }
 __global__ void __launch_bounds__(256) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
     __shared__ HornerLds L;
     const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index, uniform
+    const bool lane0 = (threadIdx.x & 63u) == 0;
     const ge_ext *S = wsum + (size_t)blockIdx.x * W;
     if (threadIdx.x == 0) { ge_ext t = S[W - 1]; L.c[0] = t.X; L.c[1] = t.Y; L.c[2] = t.Z; L.c[3] = t.T; }
     __syncthreads();
     for (int32_t win = (int32_t)W - 2; win >= 0; win--) {
         const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W);
-        for (uint32_t k = 0; k < shift; k++) horner_dbl(L, wv);
+        for (uint32_t k = 0; k < shift; k++) horner_dbl(L, wv, lane0);
         const ge_ext q = S[win];
-        horner_add(L, q, wv);
+        horner_add(L, q, wv, lane0);
     }
     if (threadIdx.x == 0) { ge_ext t; t.X = L.c[0]; t.Y = L.c[1]; t.Z = L.c[2]; t.T = L.c[3]; result[blockIdx.x] = t; }
 }
