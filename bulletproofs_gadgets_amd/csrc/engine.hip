@@ -116,7 +116,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_odd_start) X(k_odd_step) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_odd_start) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
@@ -156,7 +156,8 @@ struct Engine::Impl {
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
     DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, chunk_key;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, chunk_key, digits, entries1, starts1;
+    uint32_t sort_levels = 2;       // 2 = two-level sort (digits -> coarse partition -> fine sort per bin), 1 = one-level tile sort (BPG_MSM_SORT)
     uint32_t tile_shift = 6, tile_lgmax = 14, tile_threads = 256;   // sort tiles: 2^-tile_shift of an MSM's terms, at most 2^tile_lgmax (BPG_TILE_SHIFT, BPG_TILE_LGMAX, BPG_TILE_THREADS)
     uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
@@ -302,6 +303,7 @@ Engine::Engine(int device) : device_(device) {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_MSM_SORT")) { int v = std::atoi(e); if (v == 1 || v == 2) impl_->sort_levels = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_SHIFT")) { int v = std::atoi(e); if (v >= 0 && v <= 10) impl_->tile_shift = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
@@ -338,7 +340,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->gens_odd};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->gens_odd, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind[0].release(); impl_->h_blind[1].release();
     for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
@@ -496,16 +498,29 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
     uint32_t per = total / nmsm; if (per < 1) per = 1;
     int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > (int)msm_cmax) cc = (int)msm_cmax;
+    uint32_t maxseg = 1; for (uint32_t k = 0; k < S.nseg; k++) maxseg = std::max(maxseg, S.len[k]);
+    const bool two_level = sort_levels == 2;
+    // two-level sort: entry = sign | fb fine bits | 3 segment bits | index in segment -> 28 - fb index bits; at most 512 coarse bins
+    uint32_t fb = 0;
+    if (two_level) {
+        const uint32_t lgseg = ceil_log2(maxseg);
+        if (lgseg > 27) throw std::invalid_argument("msm: segment too long");
+        const uint32_t fbmax = std::min<uint32_t>(7, 28 - lgseg);
+        if (cc - 1 > (int)fbmax + 9) cc = (int)fbmax + 10;
+        fb = std::min<uint32_t>(fbmax, (uint32_t)cc - 1);
+    }
     // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
     const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
+    if (two_level && fb > cmax - 1) fb = cmax - 1;
     const uint32_t nkeys = nmsm * W * nb;
     uint32_t seg = 8; if (const char *e = std::getenv("BPG_RSEG")) seg = (uint32_t)std::atoi(e); if (seg > nb) seg = nb; const uint32_t nsegpw = nb / seg;
     const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
     // tiling plan: the segments of one MSM are contiguous; tiles never span two MSMs
     MsmPlan P; std::memset(&P, 0, sizeof P);
-    P.nmsm = nmsm; P.W = W; P.nb = nb;
+    P.nmsm = nmsm; P.W = W; P.nb = nb; P.fb = fb; P.CB = nb >> fb;
     {
         uint32_t lg = ceil_log2(per) > tile_shift ? ceil_log2(per) - tile_shift : 0; if (lg < 10) lg = 10; if (lg > tile_lgmax) lg = tile_lgmax;
+        if (two_level) lg = 12;                                 // k_msm_scatter1 stages one tile of entries in LDS (MSM_TILE1_MAX)
         P.lgTile = lg;
         uint32_t k = 0;
         for (uint32_t m = 0; m < nmsm; m++) {
@@ -518,29 +533,51 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
             const uint32_t nt = cdiv(P.term_start[m + 1] - P.term_start[m], 1u << lg);
             P.tile_start[m + 1] = P.tile_start[m] + nt; if (nt > P.tmax) P.tmax = nt;
         }
+        if (P.tmax == 0) P.tmax = 1;
         for (uint32_t j = 0; j < W; j++) { const uint32_t bit = ((j + 1) * 254u) / W - 1; P.bias[bit >> 5] |= 1u << (bit & 31); }
     }
     const uint32_t ntiles = P.tile_start[nmsm];
-    counts.ensure((size_t)(nkeys + 1) * 4); starts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
-    blocksum.ensure((size_t)(nblocks + 1) * 4);
+    starts.ensure((size_t)(nkeys + 1) * 4);
     entries.ensure((size_t)(total ? total : 1) * W * 4);
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
-    tile_hist.ensure((size_t)nmsm * W * (P.tmax ? P.tmax : 1) * nb * 4);
     uint32_t lgCH = 5;                                          // balanced sweep: 2^lgCH sorted entries per thread
     if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 3 && v <= 10) lgCH = (uint32_t)v; }
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, 1u << lgCH);
     heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
     chunk_key.ensure((size_t)nchunks * 4); P.lgCH = lgCH;
-    plain.ensure((size_t)(total ? total : 1) * 32);
-    if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
-    BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
-    BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
-    BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
-    BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-    if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>());
+    if (two_level) {
+        // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
+        const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
+        if (nflat64 >= (1ull << 31)) throw std::invalid_argument("msm: too many tiles");
+        const uint32_t nflat = (uint32_t)nflat64, nblk1 = cdiv(nflat, SCAN_CHUNK), K = nmsm * W * P.CB;
+        digits.ensure((size_t)(total ? total : 1) * W * 2);
+        entries1.ensure((size_t)(total ? total : 1) * W * 4);
+        counts.ensure((size_t)(nflat + 1) * 4); starts1.ensure((size_t)(nflat + 1) * 4); cursor.ensure((size_t)(nflat + 1) * 4);
+        blocksum.ensure((size_t)(nblk1 + 1) * 4);
+        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits.as<uint16_t>(), heavy.as<uint32_t>());
+        HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
+        if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits.as<uint16_t>(), total, counts.as<uint32_t>());
+        BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
+        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk1);
+        BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
+        if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits.as<uint16_t>(), total, starts1.as<uint32_t>(), entries1.as<uint32_t>());
+        BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(),
+                   chunk_key.as<uint32_t>());
+    } else {
+        counts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
+        blocksum.ensure((size_t)(nblocks + 1) * 4);
+        tile_hist.ensure((size_t)nmsm * W * P.tmax * nb * 4);
+        plain.ensure((size_t)(total ? total : 1) * 32);
+        if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
+        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
+        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
+        BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
+        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>());
+    }
     {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
@@ -559,7 +596,7 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
     wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
     BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(256), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw);
-    BPG_LAUNCH((*this), k_msm_horner, dim3(nmsm), dim3(256), wsums.as<ge_ext>(), d_result, W);
+    BPG_LAUNCH((*this), k_msm_horner, dim3(nmsm), dim3(64), wsums.as<ge_ext>(), d_result, W);
     HIPCHK(hipGetLastError());
 }
 

@@ -32,6 +32,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
     uint32_t nmsm, W, nb, lgTile, tmax, lgCH;
+    uint32_t fb, CB;             // two-level sort: a bucket index splits into CB coarse bins x 2^fb fine slots (nb = CB << fb)
     uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
     uint32_t tile_start[5];      // first tile of MSM m
     uint32_t bias[8];
@@ -94,6 +95,165 @@ __global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const u
         for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) row[b] = tile_lds[b];
     }
 }
+// ------------------------------------------------------------------------------------------------ two-level sort (default)
+// The one-level sort above writes every entry with its own 4-byte store at a position nobody else of the block writes near (a tile holds
+// about one entry per bucket): 8x write amplification, and a histogram matrix of tiles x buckets that is read and written three times.
+// Two levels instead:
+//   k_msm_digits    every signed digit of every term once: dig[window][term] = neg << 15 | |digit|  (2 bytes, coalesced)
+//   k_msm_count1    block (tile of 2^lgTile terms, window): LDS histogram over the CB coarse bins (top bits of the bucket index)
+//   (scan)          exclusive scan of counts1[(msm*W + window)*CB + bin][tile] in that order: where each (bin, tile) run starts
+//   k_msm_scatter1  block (tile, window): orders its entries by coarse bin in LDS and copies the runs out - consecutive lanes write
+//                   consecutive addresses; entry = neg << 31 | fine << (31 - fb) | segment << (28 - fb) | index in segment
+//   k_msm_sort2     block per coarse bin: counting sort by the fb fine bits inside the bin's own range (LDS counters, the range is written
+//                   by this block only, so its lines are completed in the XCD's L2), emits starts[] per bucket and chunk_key[]
+// The result is exactly what the one-level sort produces (entries grouped by bucket, starts[], chunk_key[]); the sweep is unchanged.
+// LDS counter increment that does not serialise when every lane of the wave holds the same key (identical scalars in consecutive terms:
+// padding generators, repeated witness values, range-proof bits): one atomic per wave then.  Returns the lane's slot.
+__device__ __forceinline__ uint32_t msm_lds_take(uint32_t *ctr, uint32_t key, bool active) {
+    const uint64_t act = __ballot(active);
+    if (act == 0ull) return 0u;
+    const uint32_t lane = threadIdx.x & 63u, lead = (uint32_t)__ffsll((unsigned long long)act) - 1u;
+    const uint32_t k0 = __shfl(key, lead, 64);
+    if (__ballot(active && key == k0) == act) {
+        uint32_t base = 0;
+        if (lane == lead) base = atomicAdd(&ctr[k0], (uint32_t)__popcll(act));
+        base = __shfl(base, lead, 64);
+        return base + (uint32_t)__popcll(act & ((1ull << lane) - 1ull));
+    }
+    return active ? atomicAdd(&ctr[key], 1u) : 0u;
+}
+__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ heavy_count) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g == 0) *heavy_count = 0;                            // list of k_bucket_combine, filled later on this stream
+    if (g >= total) return;
+    const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
+    for (uint32_t j = 0; j < P.W; j++) {
+        const int32_t d = msm_digit_biased(w, P.W, j);
+        const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+        dig[(size_t)j * total + g] = (uint16_t)((neg << 15) | mag);
+    }
+}
+__device__ __forceinline__ void msm_tile_of(const MsmPlan &P, uint32_t T, uint32_t &m, uint32_t &t, uint32_t &g0, uint32_t &g1) {
+    m = 0;
+#pragma unroll
+    for (uint32_t k = 1; k < 4; k++) if (k < P.nmsm && T >= P.tile_start[k]) m = k;
+    t = T - P.tile_start[m];
+    g0 = P.term_start[m] + (t << P.lgTile);
+    g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
+}
+#define MSM_CB_MAX 512
+__global__ void __launch_bounds__(256) k_msm_count1(MsmPlan P, const uint16_t *__restrict__ dig, uint32_t total, uint32_t *__restrict__ counts1) {
+    __shared__ uint32_t hist[MSM_CB_MAX];
+    uint32_t m, t, g0, g1; msm_tile_of(P, blockIdx.x, m, t, g0, g1);
+    const uint32_t win = blockIdx.y, mw = m * P.W + win;
+    for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const uint16_t *D = dig + (size_t)win * total;
+    for (uint32_t g = g0 + threadIdx.x; g < g1 + 63u; g += blockDim.x) {          // whole waves take part in the ballot of msm_lds_take
+        const uint32_t mag = g < g1 ? (D[g] & 0x7fffu) : 0u;
+        (void)msm_lds_take(hist, mag ? (mag - 1u) >> P.fb : 0u, mag != 0u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) counts1[((size_t)mw * P.CB + b) * P.tmax + t] = hist[b];
+}
+#define MSM_TILE1_MAX 4096
+#define MSM_TILE1_PER (MSM_TILE1_MAX / 256)
+__global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, const uint16_t *__restrict__ dig, uint32_t total,
+                                                      const uint32_t *__restrict__ starts1, uint32_t *__restrict__ entries1) {
+    __shared__ uint32_t cnt[MSM_CB_MAX], lbase[MSM_CB_MAX], gbase[MSM_CB_MAX], staged[MSM_TILE1_MAX];
+    __shared__ uint16_t sbin[MSM_TILE1_MAX];
+    __shared__ uint32_t wsum[4];
+    uint32_t m, t, g0, g1; msm_tile_of(P, blockIdx.x, m, t, g0, g1);
+    const uint32_t win = blockIdx.y, mw = m * P.W + win;
+    for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) { cnt[b] = 0; gbase[b] = starts1[((size_t)mw * P.CB + b) * P.tmax + t]; }
+    __syncthreads();
+    const uint16_t *D = dig + (size_t)win * total;
+    // one pass of LDS atomics: the slot a term takes inside its coarse bin is kept (16 terms per thread, digit | slot << 16 in a register)
+    uint32_t keep[MSM_TILE1_PER];
+#pragma unroll
+    for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
+        const uint32_t g = g0 + it * 256u + threadIdx.x;
+        const uint32_t d = g < g1 ? D[g] : 0u, mag = d & 0x7fffu;
+        const uint32_t slot = msm_lds_take(cnt, mag ? (mag - 1u) >> P.fb : 0u, mag != 0u);
+        keep[it] = d | (slot << 16);
+    }
+    __syncthreads();
+    {   // exclusive prefix of cnt[0..CB) -> lbase; CB <= 512: two values per thread, wave scans, 4 wave totals
+        const uint32_t a0 = 2 * threadIdx.x < P.CB ? cnt[2 * threadIdx.x] : 0u, a1 = 2 * threadIdx.x + 1 < P.CB ? cnt[2 * threadIdx.x + 1] : 0u;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        uint32_t incl = a0 + a1;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t k = 0; k < wv; k++) off += wsum[k];
+        const uint32_t excl = off + incl - (a0 + a1);
+        if (2 * threadIdx.x < P.CB) lbase[2 * threadIdx.x] = excl;
+        if (2 * threadIdx.x + 1 < P.CB) lbase[2 * threadIdx.x + 1] = excl + a0;
+        __syncthreads();
+    }
+    const uint32_t fmask = (1u << P.fb) - 1u;
+#pragma unroll
+    for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
+        const uint32_t g = g0 + it * 256u + threadIdx.x;
+        const uint32_t d = keep[it] & 0xffffu, mag = d & 0x7fffu;
+        if (mag) {
+            const uint32_t bkt = mag - 1u, bin = bkt >> P.fb, pos = lbase[bin] + (keep[it] >> 16);
+            const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+            staged[pos] = ((d >> 15) << 31) | ((bkt & fmask) << (31u - P.fb)) | (s << (28u - P.fb)) | i;
+            sbin[pos] = (uint16_t)bin;
+        }
+    }
+    __syncthreads();
+    const uint32_t ntot = lbase[P.CB - 1] + cnt[P.CB - 1];     // number of entries of the tile
+    for (uint32_t j = threadIdx.x; j < ntot; j += blockDim.x) { const uint32_t b = sbin[j]; entries1[gbase[b] + (j - lbase[b])] = staged[j]; }
+}
+// block per coarse bin k = (msm*W + window)*CB + bin: its entries are entries1[starts1[k*tmax], starts1[(k+1)*tmax]) (the last bin ends at
+// the grand total).  Counting sort by the fine bits; the bin's range of `entries` is written by this block alone.
+#define MSM_STASH 16384
+__global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__restrict__ starts1, uint32_t nflat, const uint32_t *__restrict__ entries1,
+                                                   uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
+    __shared__ uint32_t cnt[128];
+    __shared__ uint32_t cur[128];
+    __shared__ uint16_t slot16[MSM_STASH];                   // the slot each entry took in its bucket (bins of up to MSM_STASH entries: one atomic pass)
+    const uint32_t k = blockIdx.x, K = gridDim.x, nf = 1u << P.fb;
+    const uint32_t s0 = starts1[(size_t)k * P.tmax], s1 = k + 1 < K ? starts1[(size_t)(k + 1) * P.tmax] : starts1[nflat];
+    const bool stash = s1 - s0 <= MSM_STASH;
+    for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) cnt[f] = 0;
+    __syncthreads();
+    const uint32_t fsh = 31u - P.fb, fmask = nf - 1u;
+    for (uint32_t e = s0 + threadIdx.x; e < s1 + 63u; e += blockDim.x) {
+        const bool on = e < s1;
+        const uint32_t slot = msm_lds_take(cnt, on ? (entries1[e] >> fsh) & fmask : 0u, on);
+        if (on && stash) slot16[e - s0] = (uint16_t)slot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                  // exclusive prefix over nf <= 128 counters: two per lane
+        const uint32_t lane = threadIdx.x;
+        const uint32_t a0 = 2 * lane < nf ? cnt[2 * lane] : 0u, a1 = 2 * lane + 1 < nf ? cnt[2 * lane + 1] : 0u;
+        uint32_t incl = a0 + a1;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        const uint32_t excl = s0 + incl - (a0 + a1);
+        if (2 * lane < nf) { cur[2 * lane] = excl; starts[(size_t)k * nf + 2 * lane] = excl; }
+        if (2 * lane + 1 < nf) { cur[2 * lane + 1] = excl + a0; starts[(size_t)k * nf + 2 * lane + 1] = excl + a0; }
+        if (k + 1 == K && lane == 0) starts[(size_t)K * nf] = s1;
+    }
+    __syncthreads();
+    const uint32_t idxbits = 28u - P.fb, imask = (1u << idxbits) - 1u, chmask = (1u << P.lgCH) - 1u;
+    for (uint32_t e = s0 + threadIdx.x; e < s1 + 63u; e += blockDim.x) {
+        const bool on = e < s1;
+        const uint32_t v = on ? entries1[e] : 0u, f = (v >> fsh) & fmask;
+        const uint32_t pos = stash ? (on ? cur[f] + slot16[e - s0] : 0u) : msm_lds_take(cur, f, on);
+        if (on) {
+            entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
+            if ((pos & chmask) == 0u) chunk_key[pos >> P.lgCH] = k * nf + f;
+        }
+    }
+}
+
 // one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
 __global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys,
                                                          uint32_t *__restrict__ heavy_count) {
@@ -271,63 +431,54 @@ __global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ 
 }
 
 // Horner over the window sums, result = sum_j 2^off(j) * S_j: about 250 DEPENDENT doublings, the serial tail of every MSM.
-// One block of 4 waves per MSM; the four independent field products of each doubling / addition step are computed by the
-// four waves concurrently (each wave is on its own SIMD, its lanes all hold the same value) and exchanged through LDS.
-// A single lane needs ~2,600 instructions per doubling; here each wave issues ~1/4 of that between two barriers.
-struct HornerLds { fe c[4]; fe s[4]; };
-__device__ __forceinline__ void horner_dbl(HornerLds &L, uint32_t wv, bool lane0) {
-    // L.c = (X, Y, Z, T) -> doubled point in L.c
-    fe in = (wv == 3) ? fe_add(L.c[0], L.c[1]) : L.c[wv];          // X, Y, Z, X+Y
-    fe sq = fe_sq(in);
-    __syncthreads();
-    if (lane0) L.s[wv] = sq;                                       // XX, YY, ZZ, (X+Y)^2 (one lane stores: every lane holds the same value)
-    __syncthreads();
-    fe XX = L.s[0], YY = L.s[1];
-    fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
-    fe a, b;
-    if (wv == 1) { a = YpX; b = YmX; }                              // Y3 = YpX * YmX
-    else {
-        fe ZZ2 = fe_add(L.s[2], L.s[2]);
-        fe cT = fe_sub(ZZ2, YmX), cX = fe_sub(L.s[3], YpX);
-        if (wv == 0) { a = cX; b = cT; }                            // X3 = cX * cT
-        else if (wv == 2) { a = YmX; b = cT; }                      // Z3 = YmX * cT
-        else { a = cX; b = YpX; }                                   // T3 = cX * YpX
-    }
-    fe r = fe_mul(a, b);
-    if (lane0) L.c[wv] = r;
-    __syncthreads();
+// One wave per MSM.  A doubling (and an addition) is two rounds of four independent field products; lane r of every quad (r = lane & 3)
+// computes product r of each round and holds coordinate r of the running point (X, Y, Z, T); the quad exchanges operands with DPP
+// quad_perm moves - no LDS, no barrier.  A single lane needs ~2,600 instructions per doubling, a lane of the quad ~510: the chain is
+// issue-bound on one wave, so that ratio is the speed-up (the earlier four-wave version met at three block barriers per doubling).
+template <int K> __device__ __forceinline__ fe quad_get(const fe &x) {          // every lane of a quad reads lane K's value
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.v[j], K * 0x55, 0xf, 0xf, true);
+    return r;
 }
-__device__ __forceinline__ void horner_add(HornerLds &L, const ge_ext &q, uint32_t wv, bool lane0) {
-    // L.c += q   (extended + extended, unified formulas)
-    fe X1 = L.c[0], Y1 = L.c[1];
-    fe p;
-    if (wv == 0) p = fe_mul(fe_sub(Y1, X1), fe_sub(q.Y, q.X));      // A
-    else if (wv == 1) p = fe_mul(fe_add(Y1, X1), fe_add(q.Y, q.X)); // B
-    else if (wv == 2) p = fe_mul(fe_mul(L.c[3], q.T), FE_D2());     // C
-    else { p = fe_mul(L.c[2], q.Z); p = fe_add(p, p); }             // D
-    __syncthreads();
-    if (lane0) L.s[wv] = p;
-    __syncthreads();
-    fe A = L.s[0], B = L.s[1], C = L.s[2], D = L.s[3];
-    fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
-    fe r = (wv == 0) ? fe_mul(E, F) : (wv == 1) ? fe_mul(G, H) : (wv == 2) ? fe_mul(F, G) : fe_mul(E, H);
-    if (lane0) L.c[wv] = r;
-    __syncthreads();
+__device__ __forceinline__ fe quad_pick(uint32_t r, const fe &v0, const fe &v1, const fe &v2, const fe &v3) {
+    return fe_select(fe_select(v0, v1, r & 1u), fe_select(v2, v3, r & 1u), r >> 1);
 }
-__global__ void __launch_bounds__(256) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
-    __shared__ HornerLds L;
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index, uniform
-    const bool lane0 = (threadIdx.x & 63u) == 0;
+// c = coordinate r of P  ->  coordinate r of 2P
+__device__ __forceinline__ fe quad_dbl(const fe &c, uint32_t r) {
+    const fe in = fe_select(c, fe_add(quad_get<0>(c), quad_get<1>(c)), r == 3u);      // X, Y, Z, X+Y
+    const fe sq = fe_sq(in);
+    const fe XX = quad_get<0>(sq), YY = quad_get<1>(sq), ZZ = quad_get<2>(sq), SS = quad_get<3>(sq);
+    const fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    const fe cX = fe_sub(SS, YpX), cT = fe_sub(fe_add(ZZ, ZZ), YmX);
+    // X3 = cX * cT, Y3 = YpX * YmX, Z3 = YmX * cT, T3 = cX * YpX
+    return fe_mul(quad_pick(r, cX, YpX, YmX, cX), quad_pick(r, cT, YmX, cT, YpX));
+}
+// c = coordinate r of P  ->  coordinate r of P + Q; qv = lane r's second operand of the first round: (qY - qX, qY + qX, 2d qT, 2 qZ)[r]
+__device__ __forceinline__ fe quad_add(const fe &c, const fe &qv, uint32_t r) {
+    const fe X1 = quad_get<0>(c), Y1 = quad_get<1>(c);
+    const fe u = quad_pick(r, fe_sub(Y1, X1), fe_add(Y1, X1), c, c);                     // (Y1 - X1, Y1 + X1, T1, Z1)[r]: lanes 2, 3 hold Z and T
+    const fe lhs = fe_select(u, fe_select(quad_get<3>(c), quad_get<2>(c), r & 1u), r >> 1);   // r = 2 -> T1 (lane 3), r = 3 -> Z1 (lane 2)
+    const fe p = fe_mul(lhs, qv);                                                         // A, B, C, D
+    const fe A = quad_get<0>(p), B = quad_get<1>(p), C = quad_get<2>(p), D = quad_get<3>(p);
+    const fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    // X3 = E * F, Y3 = G * H, Z3 = F * G, T3 = E * H
+    return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
+}
+__global__ void __launch_bounds__(64) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
+    const uint32_t r = threadIdx.x & 3u;
     const ge_ext *S = wsum + (size_t)blockIdx.x * W;
-    if (threadIdx.x == 0) { ge_ext t = S[W - 1]; L.c[0] = t.X; L.c[1] = t.Y; L.c[2] = t.Z; L.c[3] = t.T; }
-    __syncthreads();
+    fe c;
+    { const ge_ext t = S[W - 1]; c = quad_pick(r, t.X, t.Y, t.Z, t.T); }
     for (int32_t win = (int32_t)W - 2; win >= 0; win--) {
         const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W);
-        for (uint32_t k = 0; k < shift; k++) horner_dbl(L, wv, lane0);
+        for (uint32_t k = 0; k < shift; k++) c = quad_dbl(c, r);
         const ge_ext q = S[win];
-        horner_add(L, q, wv, lane0);
+        // lane r prepares its own operand only where that costs a product (2d qT); the sums are cheap on every lane
+        const fe qv = quad_pick(r, fe_sub(q.Y, q.X), fe_add(q.Y, q.X), fe_mul(q.T, FE_D2()), fe_add(q.Z, q.Z));
+        c = quad_add(c, qv, r);
     }
-    if (threadIdx.x == 0) { ge_ext t; t.X = L.c[0]; t.Y = L.c[1]; t.Z = L.c[2]; t.T = L.c[3]; result[blockIdx.x] = t; }
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(result + blockIdx.x)[r] = c;             // ge_ext = {X, Y, Z, T}
 }
 
 }  // namespace bpg
