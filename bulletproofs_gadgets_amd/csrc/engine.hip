@@ -16,6 +16,7 @@
 #include <thread>
 #include <sched.h>
 #include "engine.hpp"
+#include "host/fe51.hpp"
 #include "hip/kernels.cuh"
 
 namespace bpg {
@@ -270,7 +271,19 @@ struct Engine::Impl {
     }
     uint64_t gens_cap = 0;
 
-    void msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result);
+    // An MSM runs on the GPU down to its W window sums per result; those (W x 128 B) travel to a pinned slot and the serial recombination
+    // sum_j 2^off(j) S_j (~254 dependent doublings of one point) and the point encoding run on the host (host/fe51.hpp).  msm() queues the
+    // kernels and the copy and returns a ticket; msm_points() is called after the stream has been synchronised.
+    struct MsmTicket { uint32_t slot, nmsm, W; };
+    static constexpr uint32_t WS_SLOTS = 8, WS_SLOT_BYTES = 4 * 128 * 128;     // nmsm <= 4, W <= 127 (c >= 2), 128 B per point
+    PinBuf h_wsums; uint32_t ws_next = 0;
+    MsmTicket msm(const MsmSegs &S, uint32_t nmsm);
+    std::vector<h51::pt> msm_points(const MsmTicket &t) const {
+        std::vector<h51::pt> out(t.nmsm);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(h_wsums.as<uint8_t>() + (size_t)t.slot * WS_SLOT_BYTES);
+        for (uint32_t m = 0; m < t.nmsm; m++) out[m] = h51::pt_horner(w + (size_t)m * t.W * 32, t.W);
+        return out;
+    }
     // Host -> device copy of caller-owned pageable memory through two pinned bounce slots.  A direct hipMemcpyAsync from pageable memory
     // lets the runtime pin the caller's pages for the DMA; several contexts uploading the SAME arrays from different threads (a pool
     // proving many witnesses of one circuit) then pin and unpin the same pages concurrently, which faulted the GPU.
@@ -493,7 +506,7 @@ void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, u
 }
 
 // ------------------------------------------------------------------------------------------------ MSM pipeline
-void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
+Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint32_t total = S.start[S.nseg];
     if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
     uint32_t per = total / nmsm; if (per < 1) per = 1;
@@ -596,8 +609,13 @@ void Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm, ge_ext *d_result) {
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
     wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
     BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(256), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw);
-    BPG_LAUNCH((*this), k_msm_horner, dim3(nmsm), dim3(64), wsums.as<ge_ext>(), d_result, W);
     HIPCHK(hipGetLastError());
+    if ((size_t)nmsm * W * sizeof(ge_ext) > WS_SLOT_BYTES) throw std::logic_error("msm: window sums exceed the host slot");
+    h_wsums.ensure((size_t)WS_SLOTS * WS_SLOT_BYTES);
+    MsmTicket t{ws_next, nmsm, W};
+    ws_next = (ws_next + 1) % WS_SLOTS;
+    HIPCHK(hipMemcpyAsync(h_wsums.as<uint8_t>() + (size_t)t.slot * WS_SLOT_BYTES, wsums.p, (size_t)nmsm * W * sizeof(ge_ext), hipMemcpyDeviceToHost, st));
+    return t;
 }
 
 namespace {
@@ -625,11 +643,9 @@ void Engine::msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const ui
     MsmSegs S = seg_new();
     seg_push(S, I.sLR.as<scm>(), I.gens.as<ge_niels>() + first, (uint32_t)count, 0);
     seg_push(S, I.sLR.as<scm>() + count, I.gens.as<ge_niels>() + gens_cap_ + first, (uint32_t)count, 0);
-    I.msm(S, 1, I.msm_result.as<ge_ext>());
-    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(out, I.comp.p, 32, hipMemcpyDeviceToHost, I.st));
+    const Impl::MsmTicket tk = I.msm(S, 1);
     HIPCHK(hipStreamSynchronize(I.st));
+    h51::pt_compress(out, I.msm_points(tk)[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ circuit upload
@@ -774,11 +790,13 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
                        I.tt_partial.as<ge_ext>());
             BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
-                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.comp.as<uint8_t>());
+                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
             HIPCHK(hipGetLastError());
             uint8_t lr[64];
-            HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
+            uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);       // L, R as extended points; encoded on the host
+            HIPCHK(hipMemcpyAsync(hp, I.msm_result.p, 2 * sizeof(ge_ext), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
+            h51::pt_compress(lr, h51::pt_from_device(hp)); h51::pt_compress(lr + 32, h51::pt_from_device(hp + 32));
             lap(tm ? &tm->ipa_msm : nullptr);
             T.append_point("L", lr); T.append_point("R", lr + 32);
             proof.insert(proof.end(), lr, lr + 64);
@@ -812,6 +830,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                            (uint32_t)g_first, (uint32_t)n, lgh, g_j, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
         BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
         BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
+        Impl::MsmTicket tk;
         {
             MsmSegs S = seg_new();
             const uint32_t lgblk = g_j ? lgh : 31u;                         // every other block of h points of the group-start tables
@@ -821,13 +840,11 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             seg_push(S, sRG, Gst, (uint32_t)cnt, 1, lgblk);
             seg_push(S, sRH, Hst + h, (uint32_t)cnt, 1, lgblk);
             seg_push(S, I.extras.as<scm>() + 4, Bn, 1, 1);
-            I.msm(S, 2, I.msm_result.as<ge_ext>());
+            tk = I.msm(S, 2);
         }
-        BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 2u);
-        HIPCHK(hipGetLastError());
         uint8_t lr[64];
-        HIPCHK(hipMemcpyAsync(lr, I.comp.p, 64, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        { const std::vector<h51::pt> LR = I.msm_points(tk); h51::pt_compress(lr, LR[0]); h51::pt_compress(lr + 32, LR[1]); }
         lap(tm ? &tm->ipa_msm : nullptr);
         T.append_point("L", lr); T.append_point("R", lr + 32);
         proof.insert(proof.end(), lr, lr + 64);
@@ -1029,6 +1046,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     // the stream of this proof was drawn ahead (a sequence of proofs: its chain ran under the previous proof's kernels) and is complete
     const bool chain_ready = bs && bs->produced.load(std::memory_order_acquire) >= 2 * n;
     const bool merged = expanded || tabled || n < 4096 || chain_ready;   // nothing to hide behind: A_I, A_O, S in one pass after the draws (one serial tail, not four)
+    Impl::MsmTicket tk_aiao{0, 0, 0}, tk_s[3]; uint32_t nparts = 0;
     if (!merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
@@ -1036,7 +1054,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
         seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
         seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
-        I.msm(S, 2, I.msm_result.as<ge_ext>());
+        tk_aiao = I.msm(S, 2);
     }
     const double t_rng0 = now_ms();
     I.h_raw.ensure((2 * n ? 2 * n : 1) * 64);
@@ -1044,10 +1062,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     scm *sL = I.sLR.as<scm>(), *sR = sL + n;
     // S = <s_L, G> + <s_R, H> + sb * B_blinding is accumulated in pieces as the draws arrive: <s_L, G> once s_L is complete,
     // the first 7/8 of <s_R, H> next, and only the last eighth (+ the blinding term) after the chain has ended.
-    I.s_parts.ensure(4 * sizeof(ge_ext));
     struct Piece { uint64_t a, b; } pieces[3] = {{0, n}, {n, n + (n - n / 8)}, {n + (n - n / 8), 2 * n}};
     if (n < (1u << 17)) { pieces[0] = {0, 0}; pieces[1] = {0, 0}; pieces[2] = {0, 2 * n}; }      // short chain: one MSM after it (each call has a ~1 ms serial tail)
-    uint32_t next_piece = 0, nparts = 0;
+    uint32_t next_piece = 0;
     auto launch_pieces = [&](uint64_t drawn) {
         while (next_piece < 3 && pieces[next_piece].b <= drawn) {
             const Piece pc = pieces[next_piece];
@@ -1058,8 +1075,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             if (pc.a < n) seg_push(S, sL + pc.a, Gtab + pc.a, (uint32_t)(std::min<uint64_t>(pc.b, n) - pc.a), 0);
             if (pc.b > n) { const uint64_t a2 = std::max<uint64_t>(pc.a, n) - n; seg_push(S, sR + a2, Htab + a2, (uint32_t)(pc.b - n - a2), 0); }
             if (last) seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 0);
-            I.msm(S, 1, I.s_parts.as<ge_ext>() + nparts);
-            nparts++;
+            tk_s[nparts++] = I.msm(S, 1);
         }
     };
     if (expanded) {     // (include/bpg.h): one draw K, the 2n scalars are expanded from it on the device
@@ -1096,12 +1112,18 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     }
     if (tm) tm->rng_host += now_ms() - t_rng0;
     lap(tm ? &tm->msm_aiao : nullptr);
+    uint8_t pts[96];
     if (tabled) {
         const uint32_t M0 = (uint32_t)N, nblk = cdiv((uint64_t)M0 * 16, 256);
         BPG_LAUNCH(I, k_tt_commit3, dim3(nblk, 3), dim3(256), I.tt_table.as<ge_pniels>(), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR,
                    (uint32_t)n, M0, I.tt_partial.as<ge_ext>());
         BPG_LAUNCH(I, k_tt_commit3_finish, dim3(3), dim3(256), I.tt_partial.as<ge_ext>(), nblk, I.extras.as<scm>(),
                    I.ped_table.as<ge_pniels>() + (size_t)TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
+        HIPCHK(hipGetLastError());
+        uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);           // three extended points; encoded on the host
+        HIPCHK(hipMemcpyAsync(hp, I.msm_result.p, 3 * sizeof(ge_ext), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int k = 0; k < 3; k++) h51::pt_compress(pts + 32 * k, h51::pt_from_device(hp + 32 * k));
     } else if (merged) {
         MsmSegs S = seg_new();
         seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
@@ -1112,16 +1134,18 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         seg_push(S, sL, Gtab, (uint32_t)n, 2);
         seg_push(S, sR, Htab, (uint32_t)n, 2);
         seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
-        I.msm(S, 3, I.msm_result.as<ge_ext>());
+        const Impl::MsmTicket tk = I.msm(S, 3);
+        HIPCHK(hipStreamSynchronize(st));
+        const std::vector<h51::pt> P3 = I.msm_points(tk);
+        for (int k = 0; k < 3; k++) h51::pt_compress(pts + 32 * k, P3[k]);
     } else {
         launch_pieces(2 * n);
-        BPG_LAUNCH(I, k_sum_points, dim3(1), dim3(64), I.s_parts.as<ge_ext>(), nparts, I.msm_result.as<ge_ext>() + 2);
+        HIPCHK(hipStreamSynchronize(st));
+        const std::vector<h51::pt> AB = I.msm_points(tk_aiao);
+        h51::pt Sp = I.msm_points(tk_s[0])[0];
+        for (uint32_t k = 1; k < nparts; k++) Sp = h51::pt_add(Sp, I.msm_points(tk_s[k])[0]);
+        h51::pt_compress(pts, AB[0]); h51::pt_compress(pts + 32, AB[1]); h51::pt_compress(pts + 64, Sp);
     }
-    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 3u);
-    HIPCHK(hipGetLastError());
-    uint8_t pts[96];
-    HIPCHK(hipMemcpyAsync(pts, I.comp.p, 96, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
     lap(tm ? &tm->msm_s : nullptr);
 
     std::vector<uint8_t> proof;
@@ -1318,20 +1342,18 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
         hs[o++] = to_scm(-eb - r * txb);                                              // B_blinding
     }
     HIPCHK(hipMemcpyAsync(I.vfy_sc.p, hs.data(), hs.size() * sizeof(scm), hipMemcpyHostToDevice, st));
-    I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
+    Impl::MsmTicket tk;
     {
         MsmSegs S = seg_new();
         seg_push(S, gsc, I.gens.as<ge_niels>(), (uint32_t)N, 0);
         seg_push(S, hsc, I.gens.as<ge_niels>() + gens_cap_, (uint32_t)N, 0);
         seg_push(S, I.vfy_sc.as<scm>(), I.vfy_pts.as<ge_niels>(), npts, 0);
         seg_push(S, I.vfy_sc.as<scm>() + npts, I.bases.as<ge_niels>(), 2, 0);
-        I.msm(S, 1, I.msm_result.as<ge_ext>());
+        tk = I.msm(S, 1);
     }
-    BPG_LAUNCH(I, k_compress, dim3(1), dim3(64), I.msm_result.as<ge_ext>(), I.comp.as<uint8_t>(), 1u);
-    HIPCHK(hipGetLastError());
-    uint8_t out[32];
-    HIPCHK(hipMemcpyAsync(out, I.comp.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    uint8_t out[32];
+    h51::pt_compress(out, I.msm_points(tk)[0]);
     return is_ident(out) ? R1CSError::None : R1CSError::VerificationError;
 }
 

@@ -257,9 +257,9 @@ __global__ void __launch_bounds__(256) k_tt_commit3_finish(const ge_ext *__restr
     }
     if (threadIdx.x == 0) out[cls] = lds[0];
 }
-// block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>, compress
+// block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>; the point goes to the host, which encodes it
 __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ a, const scm *__restrict__ b,
-                                                   uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, uint8_t *__restrict__ out) {
+                                                   uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, ge_ext *__restrict__ out) {
     __shared__ ge_ext lds[256];
     __shared__ scm slds[256];
     const uint32_t cls = blockIdx.x;
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ pa
         if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) ge_compress(out + 32 * cls, lds[0]);
+    if (threadIdx.x == 0) out[cls] = lds[0];
 }
 
 // Pedersen commitments v*B + r*B_blinding from the window tables of the two fixed bases (k_tt_bases / k_tt_multiples on

@@ -3,6 +3,7 @@
 // Not part of the product library; the product has no CPU execution path.
 #include "../../bulletproofs_gadgets_amd/csrc/hip/ge.cuh"
 #include "../../bulletproofs_gadgets_amd/csrc/hip/sc.cuh"
+#include "../../bulletproofs_gadgets_amd/csrc/host/fe51.hpp"
 #include <string.h>
 using namespace bpg;
 
@@ -53,5 +54,48 @@ void hc_scalarmul_uniform(uint8_t *out, const uint8_t *k32, const uint8_t *in64)
     acc = ge_add(ge_msub(acc, Pn), P);
     acc = ge_madd_signed(ge_madd_signed(acc, Pn, 1), Pn, 0);
     ge_compress(out, acc);
+}
+// ---- host/fe51.hpp (the serial epilogues of the product: Horner recombination and point encoding on the host)
+// op as hc_fe_op (0 mul 1 sq 2 add 3 sub 4 neg 6 pow22523 7 freeze), inputs raw 256-bit values as the device hands them over
+void hc_fe51_op(int op, uint8_t *out, const uint8_t *a, const uint8_t *b) {
+    uint32_t wa[8], wb[8]; memcpy(wa, a, 32); memcpy(wb, b, 32);
+    h51::fe51 x = h51::fe_from_words(wa), y = h51::fe_from_words(wb), r;
+    switch (op) {
+    case 0: r = h51::fe_mul(x, y); break;
+    case 1: r = h51::fe_sq(x); break;
+    case 2: r = h51::fe_add(x, y); break;
+    case 3: r = h51::fe_sub(x, y); break;
+    case 4: r = h51::fe_neg(x); break;
+    case 6: r = h51::fe_pow22523(x); break;
+    default: r = x; break;
+    }
+    h51::fe_tobytes(out, r);
+}
+// the same point through the device-side formulas (portable forms) and through fe51: k*P built with ge_dbl / ge_madd, then encoded by both;
+// also 2^shift * P + Q through pt_dbl / pt_add against ge_dbl / ge_add.  Returns 1 when every pair of encodings agrees.
+int hc_fe51_point_check(uint8_t *out_dev, uint8_t *out_h51, const uint8_t *k32, const uint8_t *in64, int shift) {
+    uint32_t w[16]; memcpy(w, in64, 64);
+    ge_ext P = ge_from_uniform_words(w);
+    ge_niels Pn = ge_to_niels(P, fe_invert(P.Z));
+    ge_ext acc = ge_identity();
+    for (int i = 255; i >= 0; i--) { acc = ge_dbl(acc); if ((k32[i / 8] >> (i % 8)) & 1) acc = ge_madd(acc, Pn); }
+    uint32_t raw[32]; memcpy(raw, &acc, 128);
+    h51::pt hp = h51::pt_from_device(raw);
+    ge_compress(out_dev, acc); h51::pt_compress(out_h51, hp);
+    int ok = memcmp(out_dev, out_h51, 32) == 0;
+    ge_ext d = acc; h51::pt hd = hp;
+    for (int i = 0; i < shift; i++) { d = ge_dbl(d); hd = h51::pt_dbl(hd); }
+    d = ge_add(d, P); memcpy(raw, &P, 128); hd = h51::pt_add(hd, h51::pt_from_device(raw));
+    uint8_t e1[32], e2[32]; ge_compress(e1, d); h51::pt_compress(e2, hd);
+    ok &= memcmp(e1, e2, 32) == 0;
+    // Horner over W = 3 "window sums" (acc, P, d): sum_j 2^off(j) S_j with off = j * 254 / 3
+    ge_ext S[3] = {acc, P, d};
+    uint32_t sw[96]; memcpy(sw, S, 384);
+    h51::pt hh = h51::pt_horner(sw, 3);
+    ge_ext r = S[2];
+    for (int win = 1; win >= 0; win--) { int sh = ((win + 1) * 254) / 3 - (win * 254) / 3; for (int i = 0; i < sh; i++) r = ge_dbl(r); r = ge_add(r, S[win]); }
+    ge_compress(e1, r); h51::pt_compress(e2, hh);
+    ok &= memcmp(e1, e2, 32) == 0;
+    return ok;
 }
 }

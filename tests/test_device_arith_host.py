@@ -17,7 +17,7 @@ P, L = R.P, R.L
 def hc():
     so = HERE / "hostcheck" / "libhostcheck.so"
     src = HERE / "hostcheck" / "hostcheck.cpp"
-    hdrs = list((HERE.parent / "bulletproofs_gadgets_amd" / "csrc" / "hip").glob("*.cuh"))
+    hdrs = list((HERE.parent / "bulletproofs_gadgets_amd" / "csrc" / "hip").glob("*.cuh")) + [HERE.parent / "bulletproofs_gadgets_amd" / "csrc" / "host" / "fe51.hpp"]
     if not so.exists() or any(p.stat().st_mtime > so.stat().st_mtime for p in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", str(so), str(src)])
     return C.CDLL(str(so))
@@ -90,3 +90,25 @@ def test_elligator_compress_and_group_law(hc, golden):
         k = (int.from_bytes(rnd(b"k", i), "little") % L) if i else 0
         hc.hc_scalarmul_uniform(out, k.to_bytes(32, "little"), u)
         assert out.raw == O.point_mul(k.to_bytes(32, "little"), pt), i
+
+
+def test_host_fe51_matches_bigint_and_device_forms(hc):
+    """host/fe51.hpp (radix 2^51; the product's serial epilogues: Horner recombination of an MSM's window sums and RFC 9496 encoding on the
+    host) against Python big-ints on raw device-form inputs, and against the device-side formulas on whole points."""
+    vals = EDGE + [int.from_bytes(rnd(b"fe51", i), "little") for i in range(60)]
+    out = C.create_string_buffer(32)
+    ops = {0: lambda a, b: a * b, 1: lambda a, b: a * a, 2: lambda a, b: a + b, 3: lambda a, b: a - b, 4: lambda a, b: -a, 7: lambda a, b: a}
+    for i, a in enumerate(vals):
+        for b in (vals[(i * 7 + 3) % len(vals)], vals[(i * 13 + 5) % len(vals)], EDGE[i % len(EDGE)]):
+            for op, f in ops.items():
+                hc.hc_fe51_op(op, out, a.to_bytes(32, "little"), b.to_bytes(32, "little"))
+                assert int.from_bytes(out.raw, "little") == f(a, b) % P, (op, hex(a), hex(b))
+    for a in vals[:30]:
+        hc.hc_fe51_op(6, out, a.to_bytes(32, "little"), bytes(32))
+        assert int.from_bytes(out.raw, "little") == pow(a % P, (P - 5) // 8, P)
+    o1, o2 = C.create_string_buffer(32), C.create_string_buffer(32)
+    for i in range(16):
+        u = rnd(b"uni51", i, 64)
+        k = (int.from_bytes(rnd(b"k51", i), "little") % L) if i else 0          # k = 0: the identity, encoded as 32 zero bytes
+        assert hc.hc_fe51_point_check(o1, o2, k.to_bytes(32, "little"), u, 1 + 7 * i) == 1, i
+        assert o1.raw == o2.raw == O.point_mul(k.to_bytes(32, "little"), O.from_uniform(u))
