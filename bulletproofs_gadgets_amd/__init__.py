@@ -458,6 +458,12 @@ class Prover:
         _chk(lib().bpg_prover_commit_many(self._h, C.c_uint64(k), b"".join(vs), b"".join(blindings), coms, vars_))
         return [coms.raw[32 * i:32 * i + 32] for i in range(k)], [Variable(vars_[i]) for i in range(k)]
 
+    def commit_precomputed(self, v: bytes, v_blinding: bytes, commitment: bytes):
+        """bpg_prover_commit_precomputed: Prover::commit with the Pedersen commitment supplied by the caller (works without a device context)."""
+        var = C.c_uint32()
+        _chk(lib().bpg_prover_commit_precomputed(self._h, _exact("v", v, 32), _exact("v_blinding", v_blinding, 32), _exact("commitment", commitment, 32), C.byref(var)))
+        return Variable(var.value)
+
     def multiply(self, left, right):
         out = (C.c_uint32 * 3)()
         l, r = LinearCombination.of(left)._c(), LinearCombination.of(right)._c()
@@ -653,6 +659,14 @@ class Gadget:
                                     C.c_uint64(len(blindings)), coms, dsc, dvars, C.byref(n)))
         k = n.value
         return [coms.raw[32 * i:32 * i + 32] for i in range(k)], [(dsc.raw[32 * i:32 * i + 32], Variable(dvars[i])) for i in range(k)]
+
+    def preprocess(self, witnesses):
+        """Gadget::preprocess (src/gadget.rs:8): the derived scalars, for a host that makes the commitments itself."""
+        cap = max(8, 2 * len(witnesses) + 2)
+        n = C.c_uint64(cap)
+        dsc = _buf(32 * cap)
+        _chk(lib().bpg_gadget_preprocess(self._h, b"".join(witnesses), C.c_uint64(len(witnesses)), dsc, C.byref(n)))
+        return [dsc.raw[32 * i:32 * i + 32] for i in range(n.value)]
 
     def prove(self, prover, commitment_vars, derived_witnesses):
         """Gadget::prove on a Prover or on a ConstraintBuffer (the dyn ConstraintSystem of the reference)."""

@@ -54,6 +54,13 @@ std::vector<Variable> Prover::commit_many(const std::vector<Scalar> &v, const st
     return vars;
 }
 
+Variable Prover::commit_precomputed(const Scalar &v, const Scalar &v_blinding, const uint8_t com[32]) {
+    const uint32_t idx = (uint32_t)v_.size();
+    v_.push_back(v); vb_.push_back(v_blinding.is_canonical() ? v_blinding : v_blinding.reduced());
+    t_->append_point("V", com);
+    return Variable{Variable::Committed, idx};
+}
+
 std::vector<uint8_t> Prover::prove(uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags) {
     if (!engine_) throw DeviceError("this prover has no device context: prove() needs the GPU engine");
     engine_->gens_ensure(gens_capacity);
@@ -327,6 +334,13 @@ bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, c
         if (vars_out) for (uint64_t i = 0; i < k; i++) vars_out[i] = vars[i].packed();
     });
 }
+bpg_status bpg_prover_commit_precomputed(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], const uint8_t com[32], uint32_t *var_out) {
+    return guard([&] {
+        REQUIRE(p && v && blind && com);
+        const Variable var = p->p->commit_precomputed(Scalar::from_bits(v), Scalar::from_bytes_mod_order(blind), com);
+        if (var_out) *var_out = var.packed();
+    });
+}
 uint64_t bpg_prover_num_constraints(const bpg_prover *p) { return p ? p->p->num_constraints() : 0; }
 uint64_t bpg_prover_num_multiplications(const bpg_prover *p) { return p ? p->p->get_num_multiplications() : 0; }
 uint64_t bpg_prover_num_committed(const bpg_prover *p) { return p ? p->p->num_committed() : 0; }
@@ -469,6 +483,18 @@ bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *wit, ui
         if (k) { REQUIRE(coms_out && derived_scalars_out && derived_vars_out); std::memcpy(coms_out, r.first.data(), k * 32); }
         for (size_t i = 0; i < k; i++) { r.second[i].first.v.to_bytes(derived_scalars_out + 32 * i); derived_vars_out[i] = r.second[i].second.packed(); }
         *n_derived = k;
+    });
+}
+bpg_status bpg_gadget_preprocess(bpg_gadget *g, const uint8_t *wit, uint64_t n_wit, uint8_t *derived_scalars_out, uint64_t *n_derived) {
+    return guard([&] {
+        REQUIRE(g && n_derived && (n_wit == 0 || wit));
+        std::vector<Scalar> w(n_wit);
+        for (uint64_t i = 0; i < n_wit; i++) w[i] = Scalar::from_bits(wit + 32 * i);
+        const std::vector<Scalar> d = g->g->preprocess(w);
+        if (d.size() > *n_derived) throw std::invalid_argument("preprocess: output capacity too small");
+        if (!d.empty()) REQUIRE(derived_scalars_out);
+        for (size_t i = 0; i < d.size(); i++) d[i].to_bytes(derived_scalars_out + 32 * i);
+        *n_derived = d.size();
     });
 }
 static std::vector<Variable> unpack_vars(const uint32_t *v, uint64_t n) { std::vector<Variable> o; for (uint64_t i = 0; i < n; i++) o.push_back(Variable::unpack(v[i])); return o; }

@@ -169,6 +169,8 @@ public:
     std::pair<std::vector<uint8_t>, Variable> commit(const Scalar &v, const Scalar &v_blinding);
     // batched form of the same call sequence (identical transcript effect, one kernel launch)
     std::vector<Variable> commit_many(const std::vector<Scalar> &v, const std::vector<Scalar> &blind, std::vector<uint8_t> &coms_out);
+    // the same for a commitment computed by the caller (no device context needed): registers the variable, appends "V"
+    Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const uint8_t com[32]);
 
     MulVars multiply(LinearCombination left, LinearCombination right) override {
         Scalar l = eval(left), r = eval(right), o = l * r;

@@ -157,6 +157,9 @@ bpg_status bpg_prover_new(bpg_ctx *ctx, bpg_transcript *t, bpg_prover **out);   
 void bpg_prover_free(bpg_prover *p);
 bpg_status bpg_prover_commit(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], uint8_t com_out[32], uint32_t *var_out);
 bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, const uint8_t *blind, uint8_t *coms_out, uint32_t *vars_out);
+/* Prover::commit for a host that computes its Pedersen commitments elsewhere (its own PedersenGens, or a prover created without a device
+ * context): registers (v, blind) as the next committed variable and appends the given 32-byte commitment to the transcript as "V". */
+bpg_status bpg_prover_commit_precomputed(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], const uint8_t com[32], uint32_t *var_out);
 uint64_t bpg_prover_num_constraints(const bpg_prover *p);                                       /* fork getter, prover.rs:89 */
 uint64_t bpg_prover_num_multiplications(const bpg_prover *p);                                   /* fork getter, prover.rs:92 */
 uint64_t bpg_prover_num_committed(const bpg_prover *p);
@@ -207,6 +210,8 @@ void bpg_gadget_free(bpg_gadget *g);
 /* Gadget::setup: derived = preprocess(witnesses); one commitment each. *n_derived: in = capacity, out = count */
 bpg_status bpg_gadget_setup(bpg_gadget *g, bpg_prover *p, const uint8_t *witness_scalars, uint64_t n_wit, const uint8_t *blindings,
                             uint64_t n_blind, uint8_t *coms_out, uint8_t *derived_scalars_out, uint32_t *derived_vars_out, uint64_t *n_derived);
+/* Gadget::preprocess alone: the derived scalars a host commits itself (bpg_prover_commit / bpg_prover_commit_precomputed), in order */
+bpg_status bpg_gadget_preprocess(bpg_gadget *g, const uint8_t *witness_scalars, uint64_t n_wit, uint8_t *derived_scalars_out, uint64_t *n_derived);
 bpg_status bpg_gadget_prove(bpg_gadget *g, bpg_prover *p, const uint32_t *vars, uint64_t n_vars, const uint8_t *derived_scalars,
                             const uint32_t *derived_vars, uint64_t n_derived);
 bpg_status bpg_gadget_verify(bpg_gadget *g, bpg_verifier *v, const uint32_t *vars, uint64_t n_vars, const uint32_t *derived_vars, uint64_t n_derived);

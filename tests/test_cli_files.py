@@ -53,6 +53,23 @@ def test_prover_then_verifier(ctx, tmp_path, name):
         if CASES[name][2] is not None:
             assert p.num_committed() == CASES[name][2]
     assert (tmp_path / (name + ".proof")).read_bytes() == proof
+    if p.get_num_multiplications() <= (1 << 14):
+        # byte parity with the oracle PROVER on what the driver assembled (cfg 1: the README example at N = 2^14 takes the oracle ~2 s)
+        inst = p.instance()
+        pre = bpg.Transcript(stem.encode())
+        pre.append_message(b"dom-sep", b"r1cs v1")                              # Prover::new
+        for k in range(inst.m):
+            pre.append_message(b"V", bytes.fromhex((tmp_path / (name + ".coms")).read_text().splitlines()[k].split("0x")[1]))
+        oc_p = O.FlatCircuit(inst.n, inst.m, inst.aL, inst.aR, inst.aO, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+        rc, want, _ = O.prove(O.Gens(cli.round_pow2(inst.n)), pre.state, oc_p, inst.v_blinding, bytes(32), O.FLAG_FAST_MSM)
+        assert rc == 0 and proof == want, "%s: the driver's proof differs from the oracle prover's" % name
+    if name == "example":
+        import hashlib, json
+        fix = json.loads((RES.parent / "assembly.json").read_text())["example_gadgets"]
+        p2, _ = cli.prover(stem, ctx=ctx, seed=fix["blinding_seed"].encode(), rng_seed=bytes(32), quiet=True)
+        # the .coms file the GPU driver writes under the fixture's blinding seed is the one the independent Python restatement wrote
+        assert hashlib.sha256((tmp_path / (name + ".coms")).read_bytes()).hexdigest() == fix["coms_file_sha256"]
+        p, proof = cli.prover(stem, ctx=ctx, seed=b"cli-test", rng_seed=bytes(32), quiet=True)
     coms = (tmp_path / (name + ".coms")).read_text().splitlines()
     assert len(coms) == p.num_committed() and all(l.startswith(("C", "D")) and " = 0x" in l for l in coms)
     # verifier side: assembled only from .gadgets/.inst/.coms
