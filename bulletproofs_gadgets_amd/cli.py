@@ -85,8 +85,30 @@ def parse_tree(text):
     return inst, wit, pat
 
 
-def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
+def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_pass=None):
+    """two_pass (default: on, BPG_CLI_TWO_PASS=0 turns it off): every commitment of the .gadgets file is made first (pass 1: Gadget::setup's
+    derived witnesses and hash_witness's images depend on witness and instance bytes only), the TranscriptRng chain of prove() starts on the
+    context's chain worker as soon as the transcript is final (Prover.start_blinding), and pass 2 assembles the constraints beside it, replaying
+    the cached commitments.  Same blinding draws, same .coms lines, same transcript, same proof bytes as the reference's single pass."""
     ctx = ctx or Context(0)
+    if two_pass is None:
+        two_pass = os.environ.get("BPG_CLI_TWO_PASS", "1") != "0"
+    rng_seed = rng_seed if rng_seed is not None else os.urandom(32)
+    st = {"pass": 0, "cache": [], "pos": 0, "est": 0, "or": False}
+
+    def cached(make):
+        """a commitment step: performed in the single pass and in pass 1 (remembered there), replayed in pass 2"""
+        if st["pass"] == 2:
+            r = st["cache"][st["pos"]]; st["pos"] += 1
+            return r
+        r = make()
+        if st["pass"] == 1:
+            st["cache"].append(r)
+        return r
+
+    def assemble(g, cs, vars_, derived):
+        if st["pass"] != 1:
+            g.prove(cs, vars_, derived)
     rnd = _Blindings(seed)
     transcript = Transcript(name.encode())
     p = Prover(ctx, transcript)
@@ -100,6 +122,8 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             coms_lines.append("C%s-%d = 0x%s\n" % (wname[1:], k, c.hex()))
 
     def derived_lines(coms, index, sub):                                  # assignment_parser.rs:198-211
+        if st["pass"] == 2:
+            return
         for k, c in enumerate(coms):
             coms_lines.append("D%d-%d-%d = 0x%s\n" % (index, sub, k, c.hex()))
 
@@ -118,10 +142,11 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
     def hash_witness(wn, index, sub, cs):                                 # prover.rs:160-190 -> (image scalar, image Variable)
         w = witness[wn]
         image = mimc_hash(w[3])
-        _, image_com, image_var = commit_single(p, scalar_to_be(image), rnd.next())
+        _, image_com, image_var = cached(lambda: commit_single(p, scalar_to_be(image), rnd.next()))
         hg = MimcHash256(image_var)
-        dcoms, derived = hg.setup(p, w[0], rnd.take(2))
-        hg.prove(cs, w[2], derived)
+        dcoms, derived = cached(lambda: hg.setup(p, w[0], rnd.take(2)))
+        assemble(hg, cs, w[2], derived)
+        st["est"] += 972 * (len(w[0]) + 1)
         derived_lines([image_com] + dcoms, index, sub)
         return image, image_var
 
@@ -136,30 +161,34 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             w = single(parts[1])
             lo, hi = instance[parts[2]], instance[parts[3]]
             g = BoundsCheck(lo, hi)
-            dcoms, derived = g.setup(p, w[0], rnd.take(2))
-            g.prove(cs, w[2], derived)
+            st["est"] += 16 * len(hi)
+            dcoms, derived = cached(lambda: g.setup(p, w[0], rnd.take(2)))
+            assemble(g, cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "HASH":                                                # prover.rs:278-305
             g = MimcHash256(lc_of(parts[1]))
             w = witness[parts[2]]
-            dcoms, derived = g.setup(p, w[0], rnd.take(2))
-            g.prove(cs, w[2], derived)
+            st["est"] += 972 * (len(w[0]) + 1)
+            dcoms, derived = cached(lambda: g.setup(p, w[0], rnd.take(2)))
+            assemble(g, cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "MERKLE":                                              # prover.rs:307-339
             root = lc_of(parts[1])
             inst_names, wit_names, pattern = parse_tree(line.split(None, 2)[2])
             inst_lcs = [mimc_hash(instance[i]) for i in inst_names]
             wit_lcs = [hash_witness(wn, index, sub, cs)[1] for sub, wn in enumerate(wit_names)]
-            MerkleTree256(root, inst_lcs, wit_lcs, pattern).prove(cs, [], [])
+            st["est"] += 1944 * pattern.count("(")
+            assemble(MerkleTree256(root, inst_lcs, wit_lcs, pattern), cs, [], [])
         elif op == "EQUALS":                                              # prover.rs:340-358 (grammar: W I | I W | W W)
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
             right_lcs = witness[right][2] if right[0] == "W" else be_to_scalars(instance[right])
-            Equality(right_lcs).prove(cs, witness[left][2], [])
+            assemble(Equality(right_lcs), cs, witness[left][2], [])
         elif op == "LESS_THAN":                                           # prover.rs:360-382
             l, r = single(parts[1]), single(parts[2])
             g = LessThan(l[2][0], l[0][0], r[2][0], r[0][0])
-            dcoms, derived = g.setup(p, [], rnd.take(2))
-            g.prove(cs, [], derived)
+            st["est"] += 379
+            dcoms, derived = cached(lambda: g.setup(p, [], rnd.take(2)))
+            assemble(g, cs, [], derived)
             derived_lines(dcoms, index, 0)
         elif op == "UNEQUAL":                                             # prover.rs:384-418
             left, right = (parts[1], parts[2]) if parts[1][0] == "W" else (parts[2], parts[1])
@@ -169,8 +198,9 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             else:
                 rs_ = be_to_scalars(instance[right]); rl = rs_
             g = Inequality(rl, rs_)
-            dcoms, derived = g.setup(p, lw[0], rnd.take(2 * len(lw[0]) + 1))
-            g.prove(cs, lw[2], derived)
+            st["est"] += 2 * len(lw[0]) + 1
+            dcoms, derived = cached(lambda: g.setup(p, lw[0], rnd.take(2 * len(lw[0]) + 1)))
+            assemble(g, cs, lw[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "SET_MEMBER":                                          # prover.rs:420-532
             member, elems = parts[1], parts[2:]
@@ -208,8 +238,9 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
                     else:
                         h = mimc_hash(instance[e]); i_lcs.append(h); i_scalars.append(h)
             g = SetMembership(m_lc, m_scalar, i_lcs, i_scalars)
-            dcoms, derived = g.setup(p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars)))
-            g.prove(cs, w_vars, derived)
+            st["est"] += 2 * (len(w_scalars) + len(i_scalars))
+            dcoms, derived = cached(lambda: g.setup(p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars))))
+            assemble(g, cs, w_vars, derived)
             derived_lines(dcoms, index, 0)
         else:
             raise ValueError("unknown gadget line: %r" % line)
@@ -225,6 +256,13 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
             op = parts[0]
             if closing is not None and op == closing:
                 return i
+            if st["pass"] == 1:                                           # commitments only: OR clauses are walked in file order, nothing is recorded
+                if op == "OR":
+                    st["or"] = True
+                    i = run_block(i, cs, "]")
+                elif op not in ("}", "[", "{"):
+                    do_gadget(line, index, cs)
+                continue
             if op == "}":
                 cs.rewind()                                               # end of a clause
             elif op == "OR":
@@ -238,11 +276,20 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False):
         if closing is not None:
             raise ValueError("unexpected end of input")
         return i
-    run_block(0, p, None)
+    if two_pass and hasattr(p, "start_blinding"):
+        st["pass"] = 1
+        run_block(0, p, None)
+        est = st["est"] + 64
+        p.start_blinding(rng_seed, 2 * est + 65536 if st["or"] else est)  # sizes the pinned buffer; a stream that is too short is simply not used
+        st["pass"] = 2
+        run_block(0, p, None)
+        assert st["pos"] == len(st["cache"]), "pass 2 did not use every commitment of pass 1"
+    else:
+        run_block(0, p, None)
     if not quiet:
         print(p.num_constraints())                                        # prover.rs:89
     cap = round_pow2(p.get_num_multiplications())
-    proof = p.prove(BulletproofGens(ctx, cap), rng_seed if rng_seed is not None else os.urandom(32), flags)
+    proof = p.prove(BulletproofGens(ctx, cap), rng_seed, flags)
     with open(name + ".coms", "w") as f:
         f.writelines(coms_lines)
     with open(name + ".proof", "wb") as f:
@@ -364,6 +411,13 @@ def assemble_verifier(name):
             op = parts[0]
             if closing is not None and op == closing:
                 return i
+            if st["pass"] == 1:                                           # commitments only: OR clauses are walked in file order, nothing is recorded
+                if op == "OR":
+                    st["or"] = True
+                    i = run_block(i, cs, "]")
+                elif op not in ("}", "[", "{"):
+                    do_gadget(line, index, cs)
+                continue
             if op == "}":
                 cs.rewind()
             elif op == "OR":                                              # verifier.rs:162-186

@@ -202,26 +202,48 @@ struct BufferGuard { bpg_buffer *b = nullptr; ~BufferGuard() { if (b) bpg_buffer
 // ================================================================================================ prover (prover.rs:47-100)
 struct Witness { std::vector<Bytes> scalars, coms; std::vector<uint32_t> vars; Bytes data; };
 
+// Two passes over the .gadgets file (default; BPG_CLI_TWO_PASS=0 gives the reference's single pass).  Every commitment a gadget line makes -
+// Gadget::setup's derived witnesses, hash_witness's image - depends on witness and instance bytes only, never on constraints.  Pass 1 makes
+// them all, in file order (same transcript, same blinding draws, same .coms lines as the single pass); then the transcript is final and the
+// 2n serial TranscriptRng draws of prove() can start on the context's chain worker (bpg_prover_start_blinding) WHILE pass 2 assembles the
+// constraints, replaying the cached commitments.  Same .coms and .proof bytes; the 0.3 s chain of a 2^20 circuit hides under the assembly.
+struct Setup { std::vector<Bytes> coms, dsc; std::vector<uint32_t> dvars; };
 struct ProverRun {
     std::string name; bpg_ctx *ctx = nullptr; bpg_transcript *tr = nullptr; bpg_prover *p = nullptr;
     std::map<std::string, Bytes> instance; std::map<std::string, Witness> witness; std::vector<std::string> coms_lines, lines;
     Blindings rnd;
+    int pass = 0;                                    // 0: single pass (commit and assemble line by line); 1: commitments only; 2: assembly only
+    std::vector<Setup> cache; size_t cache_pos = 0;  // the commitments of pass 1 in the order pass 2 asks for them
+    uint64_t est_multipliers = 0; bool saw_or = false;
+
+    // Gadget::setup through the cache
+    void setup(Gadget &g, const std::vector<Bytes> &wit, size_t nblind, std::vector<Bytes> &coms, std::vector<Bytes> &dsc, std::vector<uint32_t> &dvars) {
+        if (pass == 2) { if (cache_pos >= cache.size()) fail("two-pass driver: commitment cache exhausted"); const Setup &c = cache[cache_pos++]; coms = c.coms; dsc = c.dsc; dvars = c.dvars; return; }
+        g.setup(p, wit, rnd.take(nblind), coms, dsc, dvars);
+        if (pass == 1) cache.push_back(Setup{coms, dsc, dvars});
+    }
+    void prove(Gadget &g, const Cs &cs, const std::vector<uint32_t> &vars, const std::vector<Bytes> &dsc, const std::vector<uint32_t> &dvars) { if (pass != 1) g.prove(cs, vars, dsc, dvars); }
 
     const Witness &single(const std::string &w) { const Witness &x = witness.at(w); if (x.scalars.size() != 1) fail("witness var " + w + " is longer than 32 bytes"); return x; }
     Lc lc_of(const std::string &tok) { if (tok[0] == 'W') return Lc::var(single(tok).vars[0]); const Bytes &d = instance.at(tok); if (d.size() > 32) fail("instance var " + tok + " is longer than 32 bytes"); return Lc::constant(be_to_scalar(d)); }
-    void derived_lines(const std::vector<Bytes> &coms, size_t index, int sub) { for (size_t k = 0; k < coms.size(); k++) coms_lines.push_back("D" + std::to_string(index) + "-" + std::to_string(sub) + "-" + std::to_string(k) + " = 0x" + to_hex(coms[k].data(), 32) + "\n"); }
+    void derived_lines(const std::vector<Bytes> &coms, size_t index, int sub) { if (pass == 2) return; for (size_t k = 0; k < coms.size(); k++) coms_lines.push_back("D" + std::to_string(index) + "-" + std::to_string(sub) + "-" + std::to_string(k) + " = 0x" + to_hex(coms[k].data(), 32) + "\n"); }
     uint64_t cs_next_multiplier(const Cs &cs) { return cs.b ? bpg_buffer_next_multiplier(cs.b) : bpg_prover_num_multiplications(cs.p); }
 
     // hash_witness (prover.rs:160-190): commit to the MiMC image of a witness and prove the preimage relation -> (image scalar, image var)
     std::pair<Bytes, uint32_t> hash_witness(const std::string &wn, size_t index, int sub, const Cs &cs) {
         const Witness &w = witness.at(wn);
-        Bytes image = mimc_hash(w.data), com(32), blind = rnd.next(); uint32_t var = 0;
-        Bytes image_be = scalar_to_be(image), image_sc = be_to_scalar(image_be);
-        chk(bpg_prover_commit(p, image_sc.data(), blind.data(), com.data(), &var), "Prover::commit");
+        Bytes image = mimc_hash(w.data), com(32); uint32_t var = 0;
+        if (pass == 2) { if (cache_pos >= cache.size()) fail("two-pass driver: commitment cache exhausted"); const Setup &c = cache[cache_pos++]; com = c.coms.at(0); var = c.dvars.at(0); }
+        else {
+            Bytes blind = rnd.next(), image_be = scalar_to_be(image), image_sc = be_to_scalar(image_be);
+            chk(bpg_prover_commit(p, image_sc.data(), blind.data(), com.data(), &var), "Prover::commit");
+            if (pass == 1) cache.push_back(Setup{{com}, {}, {var}});
+        }
+        est_multipliers += 972 * (w.scalars.size() + 1);
         Gadget g; new_mimc(g, Lc::var(var));
         std::vector<Bytes> dcoms, dsc; std::vector<uint32_t> dvars;
-        g.setup(p, w.scalars, rnd.take(2), dcoms, dsc, dvars);
-        g.prove(cs, w.vars, dsc, dvars);
+        setup(g, w.scalars, 2, dcoms, dsc, dvars);
+        prove(g, cs, w.vars, dsc, dvars);
         std::vector<Bytes> all{com}; all.insert(all.end(), dcoms.begin(), dcoms.end());
         derived_lines(all, index, sub);
         return {image, var};
@@ -235,11 +257,13 @@ struct ProverRun {
         if (op == "BOUND") {                                              // prover.rs:253-276
             const Witness &w = single(parts.at(1));
             new_bounds(g, instance.at(parts.at(2)), instance.at(parts.at(3)));
-            g.setup(p, w.scalars, rnd.take(2), dcoms, dsc, dvars); g.prove(cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            est_multipliers += 16 * instance.at(parts.at(3)).size();
+            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
         } else if (op == "HASH") {                                        // prover.rs:278-305
             new_mimc(g, lc_of(parts.at(1)));
             const Witness &w = witness.at(parts.at(2));
-            g.setup(p, w.scalars, rnd.take(2), dcoms, dsc, dvars); g.prove(cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            est_multipliers += 972 * (w.scalars.size() + 1);
+            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
         } else if (op == "MERKLE") {                                      // prover.rs:307-339
             Lc root = lc_of(parts.at(1));
             Tree t = parse_tree(after_two(line));
@@ -247,19 +271,21 @@ struct ProverRun {
             for (const std::string &i : t.inst) il.push_back(Lc::constant(mimc_hash(instance.at(i))));
             int sub = 0; for (const std::string &wn : t.wit) wl.push_back(Lc::var(hash_witness(wn, index, sub++, cs).second));
             new_merkle(g, root, il, wl, t.pattern);
-            g.prove(cs, {}, {}, {});
+            for (char c : t.pattern) if (c == '(') est_multipliers += 1944;
+            prove(g, cs, {}, {}, {});
         } else if (op == "EQUALS") {                                      // prover.rs:340-358 (grammar: W I | I W | W W)
             std::string left = parts.at(1), right = parts.at(2); if (left[0] != 'W') std::swap(left, right);
             std::vector<Lc> rl;
             if (right[0] == 'W') for (uint32_t v : witness.at(right).vars) rl.push_back(Lc::var(v)); else for (const Bytes &s : be_to_scalars(instance.at(right))) rl.push_back(Lc::constant(s));
             std::vector<bpg_lc> rv = views(rl);
             chk(bpg_equality_new(rv.data(), rl.size(), &g.h), "Equality::new");
-            g.prove(cs, witness.at(left).vars, {}, {});
+            prove(g, cs, witness.at(left).vars, {}, {});
         } else if (op == "LESS_THAN") {                                   // prover.rs:360-382
             const Witness &l = single(parts.at(1)), &r = single(parts.at(2));
             Lc ll = Lc::var(l.vars[0]), rl = Lc::var(r.vars[0]); bpg_lc lv{&ll.t, 1}, rv{&rl.t, 1};
             chk(bpg_less_than_new(&lv, l.scalars[0].data(), &rv, r.scalars[0].data(), &g.h), "LessThan::new");
-            g.setup(p, {}, rnd.take(2), dcoms, dsc, dvars); g.prove(cs, {}, dsc, dvars); derived_lines(dcoms, index, 0);
+            est_multipliers += 379;
+            setup(g, {}, 2, dcoms, dsc, dvars); prove(g, cs, {}, dsc, dvars); derived_lines(dcoms, index, 0);
         } else if (op == "UNEQUAL") {                                     // prover.rs:384-418
             std::string left = parts.at(1), right = parts.at(2); if (left[0] != 'W') std::swap(left, right);
             const Witness &lw = witness.at(left);
@@ -268,7 +294,8 @@ struct ProverRun {
             else { rs = be_to_scalars(instance.at(right)); for (const Bytes &s : rs) rl.push_back(Lc::constant(s)); }
             std::vector<bpg_lc> rv = views(rl); Bytes ra = join(rs);
             chk(bpg_inequality_new(rv.data(), rl.size(), ra.data(), &g.h), "Inequality::new");
-            g.setup(p, lw.scalars, rnd.take(2 * lw.scalars.size() + 1), dcoms, dsc, dvars); g.prove(cs, lw.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            est_multipliers += 2 * lw.scalars.size() + 1;
+            setup(g, lw.scalars, 2 * lw.scalars.size() + 1, dcoms, dsc, dvars); prove(g, cs, lw.vars, dsc, dvars); derived_lines(dcoms, index, 0);
         } else if (op == "SET_MEMBER") {                                  // prover.rs:420-532
             const std::string &member = parts.at(1); std::vector<std::string> elems(parts.begin() + 2, parts.end());
             std::vector<Bytes> m_scalars; std::vector<Lc> m_lcs;
@@ -293,7 +320,8 @@ struct ProverRun {
             }
             bpg_lc mv{&m_lc.t, 1}; std::vector<bpg_lc> iv = views(i_lcs); Bytes ia = join(i_scalars);
             chk(bpg_set_membership_new(&mv, m_scalar.data(), iv.data(), i_lcs.size(), ia.data(), &g.h), "SetMembership::new");
-            g.setup(p, w_scalars, rnd.take(w_scalars.size() + i_scalars.size()), dcoms, dsc, dvars); g.prove(cs, w_vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            est_multipliers += 2 * (w_scalars.size() + i_scalars.size());
+            setup(g, w_scalars, w_scalars.size() + i_scalars.size(), dcoms, dsc, dvars); prove(g, cs, w_vars, dsc, dvars); derived_lines(dcoms, index, 0);
         } else fail("unknown gadget line: '" + line + "'");
     }
 
@@ -305,6 +333,12 @@ struct ProverRun {
             if (parts.empty()) continue;
             const std::string &op = parts[0];
             if (closing && op.size() == 1 && op[0] == closing) return i;
+            if (pass == 1) {                                  // commitments only: clauses of OR blocks are walked in file order, nothing is recorded
+                if (op == "OR") { saw_or = true; i = run_block(i, cs, ']'); }
+                else if (op == "}" || op == "[" || op == "{") { }
+                else do_gadget(line, index, cs);
+                continue;
+            }
             if (op == "}") { if (!cs.b) fail("'}' outside an OR block"); chk(bpg_buffer_rewind(cs.b), "rewind"); }
             else if (op == "OR") {
                 BufferGuard child; chk(bpg_buffer_new(cs_next_multiplier(cs), 1, &child.b), "ProverBuffer::new");
@@ -338,16 +372,27 @@ struct ProverRun {
         }
         lap("witness commitments");
         lines = read_lines(name + ".gadgets");
+        Bytes rng_seed(32);
+        if (const char *e = std::getenv("BPG_CLI_RNG_SEED")) { rng_seed = from_hex(e); rng_seed.resize(32); }
+        else { std::ifstream r("/dev/urandom", std::ios::binary); if (!r.read(reinterpret_cast<char *>(rng_seed.data()), 32)) fail("cannot read /dev/urandom"); }
         Cs top; top.p = p;
-        run_block(0, top, 0);
+        const char *tp = std::getenv("BPG_CLI_TWO_PASS");
+        if (tp && std::atoi(tp) == 0) { pass = 0; run_block(0, top, 0); }
+        else {
+            pass = 1; run_block(0, top, 0);
+            lap("gadget commitments (pass 1)");
+            // the transcript is final: start the chain of prove() now.  The estimate only sizes the pinned buffer; a stream that turns out too
+            // short (OR blocks add product multipliers) is simply not used
+            uint64_t est = est_multipliers + 64; if (saw_or) est = 2 * est + 65536;
+            chk(bpg_prover_start_blinding(p, rng_seed.data(), est), "start_blinding");
+            pass = 2; run_block(0, top, 0);
+            if (cache_pos != cache.size()) fail("two-pass driver: pass 2 did not use every commitment of pass 1");
+        }
         lap("gadget assembly");
         std::printf("%llu\n", (unsigned long long)bpg_prover_num_constraints(p));          // prover.rs:89
         const uint64_t n = bpg_prover_num_multiplications(p), cap = round_pow2(n);
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         lap("generators");
-        Bytes rng_seed(32);
-        if (const char *e = std::getenv("BPG_CLI_RNG_SEED")) { rng_seed = from_hex(e); rng_seed.resize(32); }
-        else { std::ifstream r("/dev/urandom", std::ios::binary); if (!r.read(reinterpret_cast<char *>(rng_seed.data()), 32)) fail("cannot read /dev/urandom"); }
         uint64_t plen = bpg_proof_size(n, 0); Bytes proof(plen);
         chk(bpg_prover_prove(p, cap, rng_seed.data(), 0, proof.data(), &plen, nullptr), "Prover::prove");
         lap("prove (upload + proof)");

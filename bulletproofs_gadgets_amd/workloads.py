@@ -136,3 +136,28 @@ def merkle_path_files(stem: str, depth=20, wbytes=16, seed=0):
     with open(stem + ".wtns", "w") as f:
         f.write("W0 = 0x%s\n" % w0.hex())
     return depth * 1944 + 972
+
+
+def merkle_tree_files(stem: str, leaves=256, wbytes=16, seed=0):
+    """A full `leaves`-leaf MiMC Merkle tree through the FILE driver: `MERKLE I0 ((..(W0 W1)..) (..))` with every leaf a witness, each hashed
+    by hash_witness (reference src/bin/prover.rs:160-190, 307-339): n = leaves * 972 + (leaves - 1) * 1944 multipliers (256 leaves: 744,552,
+    padded to 2^20), 3 * leaves + leaves commitments.  Writes stem.gadgets/.inst/.wtns; returns n."""
+    from . import mimc_hash
+    cfg = "files-%s" % seed
+    ws = [synth(cfg, k, wbytes) for k in range(leaves)]
+    level = ["W%d" % k for k in range(leaves)]
+    pat = ["I"] * leaves
+    while len(level) > 1:
+        level = ["(%s %s)" % (level[i], level[i + 1]) for i in range(0, len(level), 2)]
+        pat = [hash_pattern(pat[i], pat[i + 1]) for i in range(0, len(pat), 2)]
+    probe = Prover(None, Transcript(b"probe"))
+    MerkleTree256(bytes(32), [mimc_hash(w) for w in ws], [], pat[0]).prove(probe, [], [])
+    root_le = probe.instance().aO[-32:]
+    with open(stem + ".gadgets", "w") as f:
+        f.write("MERKLE I0 %s\n" % level[0])
+    with open(stem + ".inst", "w") as f:
+        f.write("I0 = 0x%s\n" % root_le[::-1].hex())
+    with open(stem + ".wtns", "w") as f:
+        for k, w in enumerate(ws):
+            f.write("W%d = 0x%s\n" % (k, w.hex()))
+    return leaves * 972 + (leaves - 1) * 1944

@@ -37,6 +37,9 @@ class HostProver(bpg.Prover):
     def prove(self, *a, **k):
         return b""
 
+    def start_blinding(self, *a, **k):           # the file driver's two-pass flow (commitments first, then assembly) runs as it does on the GPU
+        self.started_blinding = True
+
 
 @pytest.fixture(autouse=True)
 def setup_without_a_device(monkeypatch):
@@ -99,7 +102,11 @@ def test_readme_example_assembly_matches_the_independent_restatement(tmp_path, m
     got = product_summary(p, p.transcript)
     for k in KEYS:
         assert got[k] == want[k], k
+    assert p.started_blinding            # two passes here (the fixture was written by a single pass in the reference's order): nothing may differ
     assert hashlib.sha256((tmp_path / "example.coms").read_bytes()).hexdigest() == want["coms_file_sha256"]
+    coms_two_pass = (tmp_path / "example.coms").read_bytes()
+    p1, _ = cli.prover("example", ctx=object(), seed=want["blinding_seed"].encode(), rng_seed=bytes(32), quiet=True, two_pass=False)
+    assert product_summary(p1, p1.transcript) == got and (tmp_path / "example.coms").read_bytes() == coms_two_pass
     assert (got["n"], got["q"], got["m"]) == (14988, 30007, 33)
 
 
