@@ -411,13 +411,6 @@ def assemble_verifier(name):
             op = parts[0]
             if closing is not None and op == closing:
                 return i
-            if st["pass"] == 1:                                           # commitments only: OR clauses are walked in file order, nothing is recorded
-                if op == "OR":
-                    st["or"] = True
-                    i = run_block(i, cs, "]")
-                elif op not in ("}", "[", "{"):
-                    do_gadget(line, index, cs)
-                continue
             if op == "}":
                 cs.rewind()
             elif op == "OR":                                              # verifier.rs:162-186
