@@ -187,10 +187,17 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
 
     def worker(k):
         try:
+            seeds = [bytes([k, i]) + bytes(30) for i in range(steps)]
             ress[k].prove(state, inst.v_blinding, bytes([k, 255]) + bytes(30), 0)       # warm-up (workspace allocation)
             start.wait()
+            # each context sequences its proofs as the headline does: the chain of its next proof is queued on its chain worker before the
+            # current one is proved; under load a proof waits for the GPU longer than a chain takes, so the chain is complete when its
+            # proof starts and A_I, A_O, S go through one multiscalar pass instead of four
+            ctxs[k].blinding_begin(state, inst.v_blinding, seeds[0], inst.n)
             for i in range(steps):
-                ress[k].prove(state, inst.v_blinding, bytes([k, i]) + bytes(30), 0)
+                if i + 1 < steps:
+                    ctxs[k].blinding_begin(state, inst.v_blinding, seeds[i + 1], inst.n)
+                ress[k].prove(state, inst.v_blinding, seeds[i], 0)
                 done_at.append(time.perf_counter())
         except Exception as e:      # noqa: BLE001
             errs.append(repr(e))

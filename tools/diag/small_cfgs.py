@@ -1,6 +1,6 @@
 """prove / verify times of the small BASELINE.json configurations (parity cases, not bench lines)"""
 import sys, time
-sys.path.insert(0, "/root/repo")
+import pathlib; sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent.parent))
 import bulletproofs_gadgets_amd as bpg
 from bulletproofs_gadgets_amd import workloads
 ctx = bpg.Context(0)
