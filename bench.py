@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
     ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / batch / CPU legs): "
                     "the process then launches nothing but the headline's kernels, which is what the rocprofv3 passes of tools/profile_round.sh want")
-    ap.add_argument("--in-flight", type=int, default=16, help="throughput leg: independent proofs in flight on ONE GPU, one engine context + host thread each (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=12, help="throughput leg: independent proofs in flight on ONE GPU, one engine context + host thread each (0 = skip)")
     ap.add_argument("--in-flight-only", action="store_true", help="only the throughput leg (for profiling the concurrent kernel mix)")
     return ap.parse_args(argv)
 

@@ -27,8 +27,8 @@ fi
 if has stats; then
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 5 --warmup 2 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err") || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
     echo "stats done"
-    # the concurrent mix of the throughput leg: 16 proofs in flight on 16 streams, kernels of different proofs share the CUs
-    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight 16 --steps 6 > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
+    # the concurrent mix of the throughput leg: 12 proofs in flight on 12 streams, kernels of different proofs share the CUs
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight 12 --steps 6 > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
     echo "in-flight stats done"
 fi
 if has pmc; then
