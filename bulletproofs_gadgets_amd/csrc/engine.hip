@@ -105,6 +105,24 @@ int32_t wnaf256(const Scalar &s, uint32_t w, int8_t d[256]) {
 
 uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; return l; }
 
+// On-disk cache of the generator tables (reference src/bin/prover.rs:92 re-derives them on every run).  Opt-in:
+// BPG_GENS_CACHE_DIR names a directory; the file gens_<capacity>.bpg holds a header and the affine Niels table [G | H] exactly as it lives
+// in HBM.  A file is used only if its header, length and checksum agree AND a sample of its points equals freshly derived ones.
+struct GensCacheHeader { char magic[8]; uint64_t version, capacity, bytes, checksum; };
+static const char kGensMagic[8] = {'B', 'P', 'G', 'G', 'E', 'N', 'S', '1'};
+uint64_t gens_checksum(const uint8_t *p, size_t n) {            // four interleaved multiply-rotate lanes over 8-byte words (about 10 GB/s): corruption, not adversaries
+    uint64_t h[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+    size_t i = 0;
+    for (; i + 32 <= n; i += 32) for (int k = 0; k < 4; k++) { uint64_t w; std::memcpy(&w, p + i + 8 * k, 8); h[k] = (h[k] ^ w) * 0x100000001b3ull; h[k] = (h[k] << 29) | (h[k] >> 35); }
+    for (; i < n; i++) h[0] = (h[0] ^ p[i]) * 0x100000001b3ull;
+    return h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (uint64_t)n;
+}
+std::string gens_cache_path(uint64_t cap) {
+    const char *dir = std::getenv("BPG_GENS_CACHE_DIR");
+    if (!dir || !*dir) return std::string();
+    return std::string(dir) + "/gens_" + std::to_string(cap) + ".bpg";
+}
+
 }  // namespace
 
 struct DeviceCircuit {
@@ -270,6 +288,10 @@ struct Engine::Impl {
         chain.reset();
     }
     uint64_t gens_cap = 0;
+    // BPG_GENS_CACHE_DIR (see gens_cache_path): load = read + checksum + upload + compare 2 x 64 sampled points with points derived afresh from
+    // the SHAKE256 stream (k_gens_derive on 128 generators); anything that does not agree falls back to the full derivation
+    bool gens_load_cached(const std::string &path, uint64_t cap);
+    void gens_store_cached(const std::string &path, uint64_t cap);
 
     // An MSM runs on the GPU down to its W window sums per result; those (W x 128 B) travel to a pinned slot and the serial recombination
     // sum_j 2^off(j) S_j (~254 dependent doublings of one point) and the point encoding run on the host (host/fe51.hpp).  msm() queues the
@@ -420,6 +442,8 @@ void Engine::gens_ensure(uint64_t capacity) {
     // GeneratorsChain: SHAKE256("GeneratorsChain" || 'G'|'H' || u32le(party = 0)), 64 bytes per generator (host squeeze,
     // a serial XOF), then 2*capacity Elligator maps + one batched normalisation on the device.
     const uint64_t cap = capacity;
+    const std::string cache_file = gens_cache_path(cap);
+    if (!cache_file.empty() && I.gens_load_cached(cache_file, cap)) { gens_cap_ = I.gens_cap = cap; return; }
     I.h_raw.ensure(2 * cap * 64);
     {   // the two chains are independent XOF streams: squeeze them on two threads; the streams are prefixes of one another across
         // capacities, so a process-wide cache keeps the longest one squeezed so far (contexts of a batch share it)
@@ -456,6 +480,61 @@ void Engine::gens_ensure(uint64_t capacity) {
     I.gens.release();
     I.gens = fresh;
     gens_cap_ = I.gens_cap = cap;
+    if (!cache_file.empty()) I.gens_store_cached(cache_file, cap);
+}
+
+bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap) {
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    const size_t bytes = (size_t)2 * cap * sizeof(ge_niels);
+    GensCacheHeader hd;
+    bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, kGensMagic, 8) == 0 && hd.version == 1 && hd.capacity == cap && hd.bytes == bytes;
+    PinBuf host;
+    if (ok) { host.ensure(bytes); ok = std::fread(host.p, 1, bytes, f) == bytes && std::fgetc(f) == EOF; }
+    std::fclose(f);
+    if (ok) ok = gens_checksum(host.as<uint8_t>(), bytes) == hd.checksum;
+    if (!ok) { host.release(); return false; }
+    DevBuf fresh; fresh.ensure(bytes);
+    HIPCHK(hipMemcpyAsync(fresh.p, host.p, bytes, hipMemcpyHostToDevice, st));
+    // sample: the first 64 generators of G and of H, derived afresh (the head of each SHAKE256 chain: 4 KB) and normalised the usual way
+    const uint32_t SAMPLE = (uint32_t)std::min<uint64_t>(64, cap);
+    uint8_t raw[2 * 64 * 64];
+    for (int which = 0; which < 2; which++) {
+        Shake256 sh; const uint8_t label[5] = {(uint8_t)(which ? 'H' : 'G'), 0, 0, 0, 0};
+        sh.absorb(reinterpret_cast<const uint8_t *>("GeneratorsChain"), 15); sh.absorb(label, 5);
+        sh.squeeze(raw + (size_t)which * SAMPLE * 64, (size_t)SAMPLE * 64);
+    }
+    small_in.ensure(sizeof raw); scratch_ext.ensure((size_t)2 * SAMPLE * sizeof(ge_ext)); comp.ensure((size_t)4 * SAMPLE * 32);
+    DevBuf smp; smp.ensure((size_t)2 * SAMPLE * sizeof(ge_niels));
+    HIPCHK(hipMemcpyAsync(small_in.p, raw, (size_t)2 * SAMPLE * 64, hipMemcpyHostToDevice, st));
+    BPG_LAUNCH((*this), k_gens_derive, dim3(cdiv(2 * SAMPLE, 256)), dim3(256), small_in.as<uint32_t>(), scratch_ext.as<ge_ext>(), 2 * SAMPLE);
+    BPG_LAUNCH((*this), k_normalize_niels, dim3(1), dim3(256), scratch_ext.as<ge_ext>(), smp.as<ge_niels>(), 2 * SAMPLE);
+    // compare encodings (the affine Niels form is unique up to the representative of each coordinate; the encoding is canonical)
+    BPG_LAUNCH((*this), k_compress_niels, dim3(cdiv(SAMPLE, 64)), dim3(64), smp.as<ge_niels>(), comp.as<uint8_t>(), SAMPLE);
+    BPG_LAUNCH((*this), k_compress_niels, dim3(cdiv(SAMPLE, 64)), dim3(64), smp.as<ge_niels>() + SAMPLE, comp.as<uint8_t>() + 32 * SAMPLE, SAMPLE);
+    BPG_LAUNCH((*this), k_compress_niels, dim3(cdiv(SAMPLE, 64)), dim3(64), fresh.as<ge_niels>(), comp.as<uint8_t>() + 64 * SAMPLE, SAMPLE);
+    BPG_LAUNCH((*this), k_compress_niels, dim3(cdiv(SAMPLE, 64)), dim3(64), fresh.as<ge_niels>() + cap, comp.as<uint8_t>() + 96 * SAMPLE, SAMPLE);
+    HIPCHK(hipGetLastError());
+    std::vector<uint8_t> enc((size_t)4 * SAMPLE * 32);
+    HIPCHK(hipMemcpyAsync(enc.data(), comp.p, enc.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    host.release(); smp.release();
+    if (std::memcmp(enc.data(), enc.data() + (size_t)2 * SAMPLE * 32, (size_t)2 * SAMPLE * 32) != 0) { fresh.release(); return false; }
+    gens.release();
+    gens = fresh;
+    return true;
+}
+void Engine::Impl::gens_store_cached(const std::string &path, uint64_t cap) {
+    const size_t bytes = (size_t)2 * cap * sizeof(ge_niels);
+    std::vector<uint8_t> host(bytes);
+    HIPCHK(hipMemcpyAsync(host.data(), gens.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    GensCacheHeader hd; std::memcpy(hd.magic, kGensMagic, 8); hd.version = 1; hd.capacity = cap; hd.bytes = bytes; hd.checksum = gens_checksum(host.data(), bytes);
+    const std::string tmp = path + ".tmp." + std::to_string((unsigned long long)now_ms());
+    FILE *f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;                                             // a cache that cannot be written is not an error
+    const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(host.data(), 1, bytes, f) == bytes;
+    if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
 }
 
 void Engine::gens_export(uint64_t first, uint64_t count, uint8_t *G_out, uint8_t *H_out) {

@@ -682,3 +682,46 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     c2.blinding_begin(state, inst.v_blinding, seeds[1], 1 << 16)
     c2.close()
     res.free()
+
+
+def test_generator_cache_on_disk(tmp_path, monkeypatch):
+    """BPG_GENS_CACHE_DIR: the table written by one context is what a second one loads (same exported generators, same
+    proof bytes); a file with a flipped byte (checksum), a truncated file, a wrong capacity in the header, and a file whose FIRST point was
+    replaced with a consistent checksum (sample comparison against freshly derived generators) are all ignored and the table is re-derived."""
+    import struct
+    monkeypatch.setenv("BPG_GENS_CACHE_DIR", str(tmp_path))
+    cap = 4096
+    path = tmp_path / ("gens_%d.bpg" % cap)
+
+    def table():
+        c = bpg.Context(0)
+        c.gens_ensure(cap)
+        g, h = c.gens_export(0, cap)
+        a = workloads.mimc_preimage(c, nbytes=100, seed=1)
+        inst = a.prover.instance()
+        proof, _ = c.upload(inst).prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)
+        c.close()
+        return g + h, proof
+    want, proof = table()                                  # derives, writes the file
+    assert path.exists() and path.stat().st_size == 40 + 2 * cap * 96
+    good = path.read_bytes()
+    assert table() == (want, proof)                        # loads it
+
+    def checksum(body):
+        M = (1 << 64) - 1
+        h = [0x9e3779b97f4a7c15, 0xc2b2ae3d27d4eb4f, 0x165667b19e3779f9, 0x27d4eb2f165667c5]
+        words = struct.unpack("<%dQ" % (len(body) // 8), body)
+        for i in range(0, len(words) - 3, 4):
+            for k in range(4):
+                x = ((h[k] ^ words[i + k]) * 0x100000001b3) & M
+                h[k] = ((x << 29) | (x >> 35)) & M
+        return (h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ len(body)) & M
+    assert struct.unpack("<Q", good[32:40])[0] == checksum(good[40:])
+    flipped = bytearray(good); flipped[40 + 96 * 1000 + 5] ^= 1
+    swapped = bytearray(good); swapped[40:40 + 96] = good[40 + 96:40 + 192]          # G_0 := G_1, checksum made consistent: only the sample check sees it
+    swapped[32:40] = struct.pack("<Q", checksum(bytes(swapped[40:])))
+    wrongcap = bytearray(good); wrongcap[16:24] = struct.pack("<Q", 2 * cap)
+    for bad in (bytes(flipped), good[:-7], bytes(swapped), bytes(wrongcap), b"", good + b"\x00"):
+        path.write_bytes(bad)
+        assert table() == (want, proof)
+        assert path.read_bytes() == good                   # the re-derived table replaced the bad file
