@@ -135,8 +135,8 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_odd_start) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_msm_horner) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
 #define X(n) KID_##n,
@@ -161,7 +161,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_bucket_chunks)); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -219,6 +219,7 @@ struct Engine::Impl {
         odd_w = fold_wnaf; odd_cap = gens_cap; odd_gens = gens.p;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
+    bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
@@ -343,6 +344,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 7)) impl_->fold_wnaf = (uint32_t)v; }
@@ -1003,7 +1005,10 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
                 const bool regs = !I.fold_from_memory && (nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15);
-                if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
+                if (2 * Mr <= I.fold_split_max && nterms >= 1 && nterms <= 7 && !I.fold_from_memory && I.fold_quad) {
+                    fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
+                    BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
+                } else if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
                     fold_kid = KID_k_fold_points_split;
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
                 } else if (regs) {

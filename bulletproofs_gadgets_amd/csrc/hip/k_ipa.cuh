@@ -474,6 +474,54 @@ __global__ void __launch_bounds__(256) k_odd_step(ge_ext *__restrict__ cur, cons
     cur[p] = ge_add(cur[p], dbl[p]);
 }
 
+// The fold of a small table (at most 64 K outputs) with FOUR LANES PER OUTPUT (k_points.cuh quad_*): 16 outputs per wave, every lane keeps
+// one coordinate of each of the (at most seven) addends in registers, plain NAF digits.  The chain per output is 253 doublings + 84 additions
+// per term as in k_fold_points_reg, but each step costs ~510 instructions on the critical wave instead of ~1,350, and 2 * Mr * 4 lanes fill
+// two waves per SIMD where k_fold_points_split needs four waves per 64 outputs that each repeat the doublings.
+#define BPG_QFOLD_VARS(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+__global__ void __launch_bounds__(256) k_fold_points_quad(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, ge_ext *__restrict__ out /* 2*Mr */,
+                                                          const uint32_t *__restrict__ naf, const FoldGroup fg) {
+    const uint32_t r = threadIdx.x & 3u;
+    uint32_t t = blockIdx.x * 64 + (threadIdx.x >> 2);
+    const bool live = t < 2 * fg.Mr;
+    if (!live) t = 2 * fg.Mr - 1;
+    const bool isH = t >= fg.Mr;
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const ge_niels *tab = isH ? H : G;
+    const uint32_t NT = fg.nterms;                           // <= 7
+#define BPG_QFOLD_LOAD(j) fe q##j = fe_zero(); if (j <= NT) q##j = quad_load_niels(tab + i + (size_t)j * fg.Mr, r);
+    BPG_QFOLD_VARS(BPG_QFOLD_LOAD)
+#undef BPG_QFOLD_LOAD
+    uint32_t bmask = 0;
+    if (fg.first_group) for (uint32_t q = 0; q < NT; q++) if (i + (q + 1) * fg.Mr >= fg.n) bmask |= 1u << q;
+    const uint32_t key = (isH ? 0x80000000u : 0u) | bmask;
+    const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
+    const bool uniform = __ballot(key != key0) == 0ull;
+    const uint32_t hsel = isH ? 2u : 0u;
+    fe c = fe_zero(); c.v[0] = (r == 1u || r == 2u) ? 1u : 0u;       // identity: (0, 1, 1, 0)
+    for (int k = fg.top; k >= 0; k--) {
+        c = quad_dbl(c, r);
+#pragma unroll 1
+        for (uint32_t q = 0; q < NT; q++) {
+            const uint32_t cls = uniform ? (uint32_t)__builtin_amdgcn_readfirstlane(hsel + ((bmask >> q) & 1u)) : hsel + ((bmask >> q) & 1u);
+            const uint32_t *d = naf + ((size_t)cls * NT + q) * 16;
+            const uint32_t nz = (d[k >> 5] >> (k & 31)) & 1u, ng = (d[8 + (k >> 5)] >> (k & 31)) & 1u;
+            if (uniform ? (__builtin_amdgcn_readfirstlane(nz) != 0) : (nz != 0)) {
+                fe Q = q1;
+                switch (q) {                                   // q is wave-uniform
+#define BPG_QFOLD_PICK(j) case j - 1: Q = q##j; break;
+                    BPG_QFOLD_VARS(BPG_QFOLD_PICK)
+#undef BPG_QFOLD_PICK
+                    default: break;
+                }
+                c = quad_madd(c, Q, ng, r);
+            }
+        }
+    }
+    c = quad_madd(c, quad_load_niels(tab + i, r), 0u, r);
+    if (live) reinterpret_cast<fe *>(out + t)[r] = c;        // ge_ext = {X, Y, Z, T}
+}
+
 // Latency variant of the same fold for small tables (2*Mr <= 64 K outputs: one wave per SIMD at most, so the kernel is one
 // dependent chain of 253 doublings + nterms * 84 additions whatever it does): the terms of an output are dealt to the FOUR
 // waves of a block (term q goes to wave q mod 4), each wave runs its own chain of doublings over its <= 4 addends with

@@ -430,55 +430,7 @@ __global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ 
     if (threadIdx.x == 0) wsum[blockIdx.x] = lds[0];
 }
 
-// Horner over the window sums, result = sum_j 2^off(j) * S_j: about 250 DEPENDENT doublings, the serial tail of every MSM.
-// One wave per MSM.  A doubling (and an addition) is two rounds of four independent field products; lane r of every quad (r = lane & 3)
-// computes product r of each round and holds coordinate r of the running point (X, Y, Z, T); the quad exchanges operands with DPP
-// quad_perm moves - no LDS, no barrier.  A single lane needs ~2,600 instructions per doubling, a lane of the quad ~510: the chain is
-// issue-bound on one wave, so that ratio is the speed-up (the earlier four-wave version met at three block barriers per doubling).
-template <int K> __device__ __forceinline__ fe quad_get(const fe &x) {          // every lane of a quad reads lane K's value
-    fe r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.v[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.v[j], K * 0x55, 0xf, 0xf, true);
-    return r;
-}
-__device__ __forceinline__ fe quad_pick(uint32_t r, const fe &v0, const fe &v1, const fe &v2, const fe &v3) {
-    return fe_select(fe_select(v0, v1, r & 1u), fe_select(v2, v3, r & 1u), r >> 1);
-}
-// c = coordinate r of P  ->  coordinate r of 2P
-__device__ __forceinline__ fe quad_dbl(const fe &c, uint32_t r) {
-    const fe in = fe_select(c, fe_add(quad_get<0>(c), quad_get<1>(c)), r == 3u);      // X, Y, Z, X+Y
-    const fe sq = fe_sq(in);
-    const fe XX = quad_get<0>(sq), YY = quad_get<1>(sq), ZZ = quad_get<2>(sq), SS = quad_get<3>(sq);
-    const fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
-    const fe cX = fe_sub(SS, YpX), cT = fe_sub(fe_add(ZZ, ZZ), YmX);
-    // X3 = cX * cT, Y3 = YpX * YmX, Z3 = YmX * cT, T3 = cX * YpX
-    return fe_mul(quad_pick(r, cX, YpX, YmX, cX), quad_pick(r, cT, YmX, cT, YpX));
-}
-// c = coordinate r of P  ->  coordinate r of P + Q; qv = lane r's second operand of the first round: (qY - qX, qY + qX, 2d qT, 2 qZ)[r]
-__device__ __forceinline__ fe quad_add(const fe &c, const fe &qv, uint32_t r) {
-    const fe X1 = quad_get<0>(c), Y1 = quad_get<1>(c);
-    const fe u = quad_pick(r, fe_sub(Y1, X1), fe_add(Y1, X1), c, c);                     // (Y1 - X1, Y1 + X1, T1, Z1)[r]: lanes 2, 3 hold Z and T
-    const fe lhs = fe_select(u, fe_select(quad_get<3>(c), quad_get<2>(c), r & 1u), r >> 1);   // r = 2 -> T1 (lane 3), r = 3 -> Z1 (lane 2)
-    const fe p = fe_mul(lhs, qv);                                                         // A, B, C, D
-    const fe A = quad_get<0>(p), B = quad_get<1>(p), C = quad_get<2>(p), D = quad_get<3>(p);
-    const fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
-    // X3 = E * F, Y3 = G * H, Z3 = F * G, T3 = E * H
-    return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
-}
-__global__ void __launch_bounds__(64) k_msm_horner(const ge_ext *__restrict__ wsum, ge_ext *__restrict__ result, uint32_t W) {
-    const uint32_t r = threadIdx.x & 3u;
-    const ge_ext *S = wsum + (size_t)blockIdx.x * W;
-    fe c;
-    { const ge_ext t = S[W - 1]; c = quad_pick(r, t.X, t.Y, t.Z, t.T); }
-    for (int32_t win = (int32_t)W - 2; win >= 0; win--) {
-        const uint32_t shift = msm_off(win + 1, W) - msm_off(win, W);
-        for (uint32_t k = 0; k < shift; k++) c = quad_dbl(c, r);
-        const ge_ext q = S[win];
-        // lane r prepares its own operand only where that costs a product (2d qT); the sums are cheap on every lane
-        const fe qv = quad_pick(r, fe_sub(q.Y, q.X), fe_add(q.Y, q.X), fe_mul(q.T, FE_D2()), fe_add(q.Z, q.Z));
-        c = quad_add(c, qv, r);
-    }
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(result + blockIdx.x)[r] = c;             // ge_ext = {X, Y, Z, T}
-}
+// The recombination of the W window sums, sum_j 2^off(j) * S_j (about 254 dependent doublings of one point), runs on the host
+// (csrc/host/fe51.hpp pt_horner): a lone wave issues such a chain at half rate, a 5 GHz core is an order of magnitude faster on it.
 
 }  // namespace bpg

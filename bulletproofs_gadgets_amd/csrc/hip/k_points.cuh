@@ -3,6 +3,55 @@
 
 namespace bpg {
 
+// ------------------------------------------------------------------------------------------------ four lanes per point
+// A latency-bound chain of point operations (the generator fold of a small table: 253 dependent doublings per output) is shortened by giving
+// a point to FOUR lanes: a doubling and an addition are two rounds of four independent field products; lane r of a quad (r = lane & 3)
+// computes product r of each round and holds coordinate r of the running point (X, Y, Z, T); operands move inside the quad with DPP
+// quad_perm (no LDS, no barrier).  About 510 instructions per doubling on the critical wave instead of 1,350.
+template <int K> __device__ __forceinline__ fe quad_get(const fe &x) {          // every lane of a quad reads lane K's value
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.v[j], K * 0x55, 0xf, 0xf, true);
+    return r;
+}
+__device__ __forceinline__ fe quad_swap01(const fe &x) {                         // lanes 0 and 1 of every quad exchange, 2 and 3 keep theirs
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)x.v[j], 0xE1, 0xf, 0xf, true);   // quad_perm:[1,0,2,3]
+    return r;
+}
+__device__ __forceinline__ fe quad_pick(uint32_t r, const fe &v0, const fe &v1, const fe &v2, const fe &v3) {
+    return fe_select(fe_select(v0, v1, r & 1u), fe_select(v2, v3, r & 1u), r >> 1);
+}
+// c = coordinate r of P  ->  coordinate r of 2P
+__device__ __forceinline__ fe quad_dbl(const fe &c, uint32_t r) {
+    const fe in = fe_select(c, fe_add(quad_get<0>(c), quad_get<1>(c)), r == 3u);      // X, Y, Z, X+Y
+    const fe sq = fe_sq(in);
+    const fe XX = quad_get<0>(sq), YY = quad_get<1>(sq), ZZ = quad_get<2>(sq), SS = quad_get<3>(sq);
+    const fe YpX = fe_add(YY, XX), YmX = fe_sub(YY, XX);
+    const fe cX = fe_sub(SS, YpX), cT = fe_sub(fe_add(ZZ, ZZ), YmX);
+    // X3 = cX * cT, Y3 = YpX * YmX, Z3 = YmX * cT, T3 = cX * YpX
+    return fe_mul(quad_pick(r, cX, YpX, YmX, cX), quad_pick(r, cT, YmX, cT, YpX));
+}
+// mixed addition with an affine Niels operand spread over the quad: qv = (y - x, y + x, 2dxy, 2)[r]; neg subtracts instead
+// (the first two exchange, the third changes sign).  c = coordinate r of P -> coordinate r of P +- Q
+__device__ __forceinline__ fe quad_madd(const fe &c, const fe &qv, uint32_t neg, uint32_t r) {
+    fe qs = fe_select(qv, quad_swap01(qv), neg);
+    qs = fe_select(qs, fe_neg(qs), neg & (uint32_t)(r == 2u));
+    const fe X1 = quad_get<0>(c), Y1 = quad_get<1>(c);
+    const fe lhs = quad_pick(r, fe_sub(Y1, X1), fe_add(Y1, X1), quad_get<3>(c), quad_get<2>(c));      // (Y1 - X1, Y1 + X1, T1, Z1)[r]
+    const fe p = fe_mul(lhs, qs);                                                                   // A, B, C, D = 2 Z1
+    const fe A = quad_get<0>(p), B = quad_get<1>(p), C = quad_get<2>(p), D = quad_get<3>(p);
+    const fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    // X3 = E * F, Y3 = G * H, Z3 = F * G, T3 = E * H
+    return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
+}
+__device__ __forceinline__ fe quad_load_niels(const ge_niels *p, uint32_t r) {     // lane r's operand of quad_madd
+    const fe *f = reinterpret_cast<const fe *>(p);                                 // ge_niels = {y + x, y - x, 2dxy}
+    fe two = fe_zero(); two.v[0] = 2;
+    return r == 3u ? two : f[r == 0u ? 1 : (r == 1u ? 0 : 2)];
+}
+
 // ------------------------------------------------------------------------------------------------ generators
 // one thread per generator: 64 uniform bytes -> Ristretto point (two Elligator maps + add), extended coordinates
 __global__ void __launch_bounds__(256) k_gens_derive(const uint32_t *__restrict__ uniform, ge_ext *__restrict__ out, uint32_t count) {

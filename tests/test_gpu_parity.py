@@ -392,17 +392,20 @@ def test_skewed_witness_distributions(ctx):
     check_against_oracle(ctx, p, t, cs, 512)
 
 
-@pytest.mark.parametrize("tt_lg,group,split,wnaf", [(0, 1, 1, 6), (0, 2, 1, 6), (0, 3, 1, 6), (0, 5, 1, 6), (3, 1, 1, 6), (3, 2, 1, 6), (3, 3, 1, 6), (5, 4, 1, 6), (8, 2, 1, 6),
-                                                     (9, 5, 1, 6), (11, 3, 1, 6), (0, 2, 0, 0), (0, 3, 0, 0), (3, 4, 0, 0), (0, 4, 1, 6),
-                                                     (0, 2, 0, 6), (0, 3, 0, 6), (3, 4, 0, 5), (0, 3, 0, 4), (0, 1, 0, 3), (0, 5, 0, 7), (6, 3, 0, 6)])
-def test_ipa_schedules_give_identical_proofs(tt_lg, group, split, wnaf, monkeypatch):
+@pytest.mark.parametrize("tt_lg,group,split,wnaf,quad", [
+    (0, 1, 1, 6, 1), (0, 2, 1, 6, 1), (0, 3, 1, 6, 1), (0, 5, 1, 6, 1), (3, 1, 1, 6, 1), (3, 2, 1, 6, 1), (3, 3, 1, 6, 1),
+    (5, 4, 1, 6, 1), (8, 2, 1, 6, 1), (9, 5, 1, 6, 1), (11, 3, 1, 6, 1), (0, 2, 0, 0, 1), (0, 3, 0, 0, 1), (3, 4, 0, 0, 1),
+    (0, 4, 1, 6, 1), (0, 2, 0, 6, 1), (0, 3, 0, 6, 1), (3, 4, 0, 5, 1), (0, 3, 0, 4, 1), (0, 1, 0, 3, 1), (0, 5, 0, 7, 1),
+    (6, 3, 0, 6, 1), (0, 3, 1, 6, 0), (3, 2, 1, 6, 0), (0, 2, 1, 6, 0), (5, 4, 1, 6, 0), (0, 4, 1, 0, 0)])
+def test_ipa_schedules_give_identical_proofs(tt_lg, group, split, wnaf, quad, monkeypatch):
     """The inner-product argument can be scheduled in many ways - generator folds grouped over `group` rounds, generators frozen
     below 2^tt_lg with window tables, or plain round-by-round folding (tt_lg = 0, group = 1).  Every schedule must give the
     oracle's bytes, including the first-round padding classes (n < N) falling on any term of a grouped fold, for each of the
-    three fold kernels (4-wave split, addends in registers, addends from memory for groups of 5) and for the width-w NAF fold of the
+    fold kernels (four lanes per output, 4-wave split, addends in registers, addends from memory for groups of 5) and for the width-w NAF fold of the
     first group against the odd multiples of the original generators (wnaf = 0: off; it replaces the register kernels there)."""
     monkeypatch.setenv("BPG_TT_LG", str(tt_lg))
     monkeypatch.setenv("BPG_FOLD_WNAF", str(wnaf))
+    monkeypatch.setenv("BPG_FOLD_QUAD", str(quad))          # small folds: four lanes per output (1) or the four-wave split kernel (0)
     monkeypatch.setenv("BPG_FOLD_GROUP", str(group))
     if not split:
         monkeypatch.setenv("BPG_FOLD_SPLIT", "0")      # addends-in-registers fold kernels instead of the 4-wave latency variant
