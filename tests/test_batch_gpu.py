@@ -101,7 +101,7 @@ def test_bench_spawns_its_own_ranks():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "8", "--batch", "4",
-                        "--no-cpu-baseline", "--in-flight", "0"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--in-flight", "2"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -110,3 +110,4 @@ def test_bench_spawns_its_own_ranks():
     assert sorted(x["rank"] for x in out["ranks_seen"]) == [0, 1]
     assert out["batch"]["proofs"] == 4 and out["batch"]["ranks"] == 2 and out["batch"]["proofs_per_rank"] == 2
     assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0
+    assert out["throughput"]["ranks_failed"] == 0 and out["throughput"]["proofs_in_flight_per_gpu"] == 2 and out["throughput"]["value"] > 0
