@@ -4,9 +4,10 @@
 One "step" = one Prover::prove (reference src/bin/prover.rs:93) of the reference's own 2^20 circuit - the full
 512-leaf MiMC Merkle tree of src/merkle_tree/merkle_tree_gadget.rs:473-545 (n = 993,384 multipliers padded to
 N = 2^20, q = 1,986,769 constraints, m = 512 commitments) - with the flattened instance and the generator tables
-already resident in HBM.  Steps are independent proofs (own seed): the serial TranscriptRng chain of step i+1 is drawn by
-the context's chain worker (one host thread) while the kernels of step i run; every chain of the K timed steps starts and
-ends inside the timed region.
+already resident in HBM.  Steps are independent proofs (own seed) proved one after the other on one HIP stream; their serial
+TranscriptRng chains (0.3 s of host work each, upstream-exact) are drawn ahead by the rank's chain worker on --chain-workers host
+threads (default 10: the GPU sets the pace; 1 = one host thread, reported as `single_stream`); every chain of the K timed steps
+starts and ends inside the timed region.
 
 `--gpus N` (N > 1) without a torchrun environment: this process spawns N ranks itself (fresh child processes, before anything
 touches torch or the GPU) and relays rank 0's line.  Under torchrun it is one rank: one process per GPU, each rank proves its
@@ -45,6 +46,8 @@ def parse_args(argv=None):
     ap.add_argument("--baseline-leaves", type=int, default=512, help="leaves of the CPU-baseline tree (512 = the headline circuit itself, about 150 s on one core; "
                     "64 -> N = 2^17, about 17 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chain-workers", type=int, default=10, help="threads of each rank's chain worker = how many proofs ahead the sequence keeps its TranscriptRng "
+                    "chains drawn (bpg_ctx_set_chain_workers): with ~10 the GPU sets the pace; 1 = one host thread, the chain of step i+1 under the kernels of step i")
     ap.add_argument("--no-prefetch", action="store_true", help="draw every chain inside its own prove call (round-1 behaviour): the GPU idles while the host draws")
     ap.add_argument("--batch", type=int, default=8, help="strong-scaling leg: this many independent proofs in total, sharded round-robin over the ranks (0 = skip)")
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
@@ -298,6 +301,7 @@ def run_rank(args):
     from bulletproofs_gadgets_amd import workloads
     from bulletproofs_gadgets_amd.batch import gather_proofs, shard_indices
     ctx = bpg.Context(device_index)
+    ctx.set_chain_workers(max(1, args.chain_workers))
     t0 = time.perf_counter()
     a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=None if rank == 0 else rank)
     inst = a.prover.instance()
@@ -324,15 +328,17 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def prove_sequence(seeds, gather_each=True):
-        """Independent proofs, one after the other on this rank's context.  With prefetch the chain of proof i+1 is queued on the chain
-        worker before proof i is proved (bpg_blinding_begin: same bytes as drawing it inside prove); no chain outlives the sequence."""
+    def prove_sequence(seeds, gather_each=True, ahead=None):
+        """Independent proofs, one after the other on this rank's context (one proving thread, one HIP stream).  With prefetch the chains of
+        the next `ahead` proofs are queued on the chain worker before proof i is proved (bpg_blinding_begin: same bytes as drawing them inside
+        prove); every chain of the sequence starts and ends inside it."""
+        ahead = args.chain_workers if ahead is None else ahead
         outs = []
-        if prefetch and seeds:
-            ctx.blinding_begin(state, inst.v_blinding, seeds[0], inst.n)
+        queued = 0
         for i, s in enumerate(seeds):
-            if prefetch and i + 1 < len(seeds):
-                ctx.blinding_begin(state, inst.v_blinding, seeds[i + 1], inst.n)
+            while prefetch and queued < len(seeds) and queued <= i + ahead:                  # streams i .. i + ahead alive (workers + 1 at most)
+                ctx.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                queued += 1
             out = res.prove(state, inst.v_blinding, s, 0)
             if dist is not None and gather_each:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
                 proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
@@ -387,9 +393,10 @@ def run_rank(args):
     batch_info = None
     if args.batch > 0 and not args.headline_only:
         mine = shard_indices(args.batch, rank, world)
+        ctx.set_chain_workers(1)
         barrier()
         t0 = time.perf_counter()
-        bouts = prove_sequence([seed_for(3000 + i) for i in mine], gather_each=False)
+        bouts = prove_sequence([seed_for(3000 + i) for i in mine], gather_each=False, ahead=1)      # one chain at a time per rank: the reference's one process per proof
         local = {i: o[0] for i, o in zip(mine, bouts)}
         if dist is not None:
             allp = gather_proofs(local, args.batch, proof_len, dist, device=coll_device)
@@ -398,10 +405,18 @@ def run_rank(args):
         barrier()
         dtb = allreduce(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
         assert len(allp) == args.batch and all(len(p) == proof_len for p in allp)
+        ctx.set_chain_workers(max(1, args.chain_workers))
+        barrier()
+        t0 = time.perf_counter()
+        prove_sequence([seed_for(3500 + i) for i in mine], gather_each=False)
+        barrier()
+        dtb_deep = allreduce(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
         batch_info = {"proofs": args.batch, "ranks": world, "proofs_per_rank": len(shard_indices(args.batch, 0, world)), "seconds": dtb,
+                      "seconds_with_all_chain_workers": dtb_deep,
                       "value": float(inst.q) * args.batch / dtb, "unit": "constraints/s", "scaling": "strong",
-                      "note": "fixed batch of independent 2^20 proofs, proof i on rank i mod N, one chain thread per rank (the reference: one prover process per "
-                              "proof, src/bin/prover.rs:47-100); speed-up = seconds at N=1 / seconds at N"}
+                      "note": "fixed batch of independent 2^20 proofs, proof i on rank i mod N. `seconds`: one chain at a time per rank (the reference: one prover "
+                              "process per proof, src/bin/prover.rs:47-100) - the strong-scaling leg, speed-up = seconds at N=1 / seconds at N; "
+                              "`seconds_with_all_chain_workers`: the same batch with every rank drawing --chain-workers chains side by side"}
 
     # ---- N > 1: the saturated figure on every GPU at once (secondary, as at N = 1): each rank keeps min(in-flight, 8) independent proofs in
     # flight on its own card; the sustained rates add up (no collective inside the leg, one all-reduce of the rates after it)
@@ -445,6 +460,21 @@ def run_rank(args):
         res.prove(state, inst.v_blinding, seed_for(5001), 0)
         kernels = collect_profile()
         gpu_ms_per_proof = sum(v["total_ms"] for v in kernels.values())
+
+    single = None
+    if not args.headline_only and prefetch and args.chain_workers > 1:
+        # the round-1 / verdict figure for continuity: the same sequence with ONE chain drawn at a time (the chain of step i+1 under the kernels of step i)
+        k1 = min(4, args.steps)
+        ctx.set_chain_workers(1)                             # ONE host thread draws: queued chains run one after the other
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s1 = prove_sequence([seed_for(i) for i in range(k1)], gather_each=False, ahead=1)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t0) / k1
+        ctx.set_chain_workers(max(1, args.chain_workers))
+        assert [o[0] for o in s1] == [o[0] for o in outs[:k1]], "the same seeds gave other bytes with one chain at a time"
+        single = {"steps": k1, "ms_per_step": dt1 * 1e3, "value": inst.q / dt1, "unit": "constraints/s",
+                  "note": "one host thread draws the chains, one at a time (round 1 measured 340 ms per step without any prefetch); same proof bytes as the timed steps"}
 
     verify_info = None
     if not args.headline_only:
@@ -527,11 +557,14 @@ def run_rank(args):
            "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
                                   % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                       "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
-                      "chain": ("the serial TranscriptRng chain of step i+1 is drawn by the context's chain worker (one host thread) while the kernels of step i run; "
-                                "all %d chains start and end inside the timed region" % args.steps) if prefetch else "every chain is drawn inside its own prove call",
+                      "chain": ("the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) of the next %d steps are drawn by the rank's "
+                                "chain worker on %d host threads while the kernels of step i run on one HIP stream; all %d chains start and end inside the "
+                                "timed region, so its first ~0.3 s are spent waiting for the first chains" % (args.chain_workers, args.chain_workers, args.steps))
+                               if prefetch else "every chain is drawn inside its own prove call",
+                      "host_threads_per_gpu": {"chain_workers": args.chain_workers if prefetch else 0, "proving": 1},
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
-           "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
+           "single_stream": single, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
            "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
     if gpu_ms_per_proof is not None:
         out["gpu_busy"] = {"kernel_ms_per_proof": gpu_ms_per_proof, "fraction_of_step": gpu_ms_per_proof / (t_step * 1e3),
@@ -569,6 +602,9 @@ def run_rank(args):
         # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
         cb["gpu_over_cpu"] = out["value"] / cb["value"]
         cb["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * cb["value"])
+        cb["gpu_side_host_threads"] = (args.chain_workers if prefetch else 0) + 1
+        if single is not None:
+            cb["single_stream_over_cpu"] = single["value"] / cb["value"]      # one GPU + two host threads against one core
         out["cpu_baseline"] = cb
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -277,6 +277,10 @@ class Context:
             raise ValueError("v_blinding must be a multiple of 32 bytes")
         _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, _seed32(rng_seed), C.c_uint64(max_multipliers)))
 
+    def set_chain_workers(self, workers: int):
+        """bpg_ctx_set_chain_workers: threads that draw queued blinding streams side by side (workers + 1 streams may be alive)."""
+        _chk(lib().bpg_ctx_set_chain_workers(self._h, C.c_uint32(workers)))
+
     def chain_cpu(self):
         """Host core the chain worker of this context last drew a blinding stream on (-1: none yet)."""
         lib().bpg_chain_cpu.restype = C.c_int32

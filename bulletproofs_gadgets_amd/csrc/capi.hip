@@ -387,6 +387,7 @@ bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[203],
     });
 }
 
+bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers) { return guard([&] { REQUIRE(ctx); ctx->engine->set_chain_workers(workers); }); }
 int32_t bpg_chain_cpu(bpg_ctx *ctx) { return ctx ? ctx->engine->chain_cpu() : -1; }
 
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t seed[32], uint32_t flags, uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings) {

@@ -238,32 +238,50 @@ struct Engine::Impl {
         std::vector<TranscriptRng> snaps;
         uint64_t max_draws = 0;
         int slot = 0; uint8_t *raw = nullptr;
+        // the worker uploads what it has drawn, block by block (UP draws = 4 MB), on the slab's own copy stream; ev[k] completes block k
+        static constexpr uint64_t UP = 65536;
+        int device = 0; hipStream_t copy_st = nullptr; uint8_t *d_raw = nullptr; std::vector<hipEvent_t> *ev = nullptr;
+        std::atomic<uint64_t> uploaded_blocks{0};
     };
-    struct ChainWorker {
-        std::thread th; std::mutex mu; std::condition_variable cv;
+    struct ChainWorker {                                     // the context's chain threads: one by default, `workers` draw queued streams side by side
+        std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
         std::deque<std::shared_ptr<BlindStream>> pending; bool quit = false;
         static void run(ChainWorker *w) {
             for (;;) {
                 std::shared_ptr<BlindStream> b;
                 { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
                 b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
+                (void)hipSetDevice(b->device);
                 TranscriptRng rng = b->snaps[0];
-                uint64_t pos = 0;
+                uint64_t pos = 0, up = 0;                                               // up: draws handed to the copy stream
+                auto upload = [&](uint64_t to) {                                        // block [up, to) -> device, then its event
+                    if (to <= up) return;
+                    const uint64_t k = up / BlindStream::UP;
+                    (void)hipMemcpyAsync(b->d_raw + 64 * up, b->raw + 64 * up, (to - up) * 64, hipMemcpyHostToDevice, b->copy_st);
+                    (void)hipEventRecord((*b->ev)[k], b->copy_st);
+                    up = to;
+                    b->uploaded_blocks.store(k + 1, std::memory_order_release);
+                };
                 for (;;) {
                     if (pos) b->snaps[pos / BlindStream::SNAP] = rng;                       // state before draw pos (snaps[0] was set by the caller)
                     b->produced.store(pos, std::memory_order_release);                  // draws [0, pos) and snapshots up to pos are published
                     if (pos >= b->max_draws || b->stop.load(std::memory_order_relaxed)) break;
                     rng.fill_draws64(b->raw + 64 * pos, BlindStream::SNAP);
                     pos += BlindStream::SNAP;
+                    if (pos % BlindStream::UP == 0) upload(pos);
                 }
+                upload(pos);                                                            // the last, shorter block (or what was drawn before a stop)
                 b->finished.store(true, std::memory_order_release);
             }
         }
     };
     std::unique_ptr<ChainWorker> chain;
-    std::deque<std::shared_ptr<BlindStream>> blinds;        // alive streams, oldest first (at most 2)
-    std::shared_ptr<BlindStream> slab_owner[2];             // last stream that wrote each pinned slab
-    PinBuf h_blind[2];
+    uint32_t chain_workers = 1;                             // threads of the chain worker (bpg_ctx_set_chain_workers / BPG_CHAIN_WORKERS); alive streams <= workers + 1
+    std::deque<std::shared_ptr<BlindStream>> blinds;        // alive streams, oldest first
+    std::vector<std::shared_ptr<BlindStream>> slab_owner;   // last stream that wrote each pinned slab (workers + 1 slabs)
+    std::vector<PinBuf> h_blind;
+    struct SlabDev { DevBuf d; hipStream_t copy_st = nullptr; std::vector<hipEvent_t> ev; };
+    std::vector<std::unique_ptr<SlabDev>> slab_dev;         // device side of each slab: the uploaded draws, the copy stream, one event per block
     int last_chain_cpu = -1;
     static void blind_stop(const std::shared_ptr<BlindStream> &b) {       // returns once the worker no longer touches b's slab
         b->stop.store(true, std::memory_order_relaxed);
@@ -285,7 +303,7 @@ struct Engine::Impl {
         if (!chain) return;
         { std::lock_guard<std::mutex> lk(chain->mu); chain->quit = true; }
         chain->cv.notify_all();
-        if (chain->th.joinable()) chain->th.join();
+        for (std::thread &t : chain->th) if (t.joinable()) t.join();
         chain.reset();
     }
     uint64_t gens_cap = 0;
@@ -344,6 +362,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("BPG_CHAIN_WORKERS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) impl_->chain_workers = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
@@ -379,7 +398,12 @@ Engine::~Engine() {
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
                       &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->gens_odd, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
-    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); impl_->h_blind[0].release(); impl_->h_blind[1].release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
+    for (auto &sd : impl_->slab_dev) {
+        if (sd->copy_st) { (void)hipStreamSynchronize(sd->copy_st); (void)hipStreamDestroy(sd->copy_st); }
+        for (hipEvent_t e : sd->ev) (void)hipEventDestroy(e);
+        sd->d.release();
+    }
     for (int k = 0; k < 2; k++) if (impl_->stage_ev[k]) (void)hipEventDestroy(impl_->stage_ev[k]);
     (void)hipStreamDestroy(impl_->st);
     delete impl_;
@@ -1050,7 +1074,8 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     Impl &I = *impl_;
     if (max_multipliers == 0) { I.blind_cancel(); return; }
     using BS = Impl::BlindStream;
-    while (I.blinds.size() >= 2) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // two alive streams at most: the oldest gives way
+    const size_t max_alive = (size_t)I.chain_workers + 1;
+    while (I.blinds.size() >= max_alive) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // the oldest gives way
     auto b = std::make_shared<BS>();
     Transcript T = after_commitments;
     T.append_u64("m", v_blinding.size());
@@ -1059,17 +1084,37 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     TranscriptRng rng = T.build_rng(v_blinding, seed);
     for (int k = 0; k < 3; k++) b->first[k] = rng.random_scalar();
     b->max_draws = ((2 * max_multipliers + BS::SNAP - 1) / BS::SNAP) * BS::SNAP;
-    // pinned slab: the one no alive stream owns; its previous owner must have left it (its uploads were synchronised by the prove() that used it)
-    b->slot = (!I.blinds.empty() && I.blinds.front()->slot == 0) ? 1 : 0;
-    if (I.slab_owner[b->slot]) { I.blind_retire(I.slab_owner[b->slot]); I.slab_owner[b->slot].reset(); }
-    I.h_blind[b->slot].ensure(b->max_draws * 64);
-    b->raw = I.h_blind[b->slot].as<uint8_t>();
+    // pinned slab: one that no alive stream owns; its previous owner must have left it (its uploads were synchronised by the prove() that used it)
+    if (I.h_blind.size() < max_alive) { I.h_blind.resize(max_alive); I.slab_owner.resize(max_alive); while (I.slab_dev.size() < max_alive) I.slab_dev.emplace_back(std::make_unique<Impl::SlabDev>()); }
+    int slot = -1;
+    for (size_t k = 0; k < max_alive && slot < 0; k++) {
+        bool used = false;
+        for (const std::shared_ptr<BS> &x : I.blinds) used |= x->slot == (int)k;
+        if (!used) slot = (int)k;
+    }
+    if (slot < 0) throw std::logic_error("blinding_begin: no free slab");
+    b->slot = slot;
+    if (I.slab_owner[slot]) { I.blind_retire(I.slab_owner[slot]); I.slab_owner[slot].reset(); }
+    Impl::SlabDev &sd = *I.slab_dev[slot];
+    if (!sd.copy_st) HIPCHK(hipStreamCreateWithFlags(&sd.copy_st, hipStreamNonBlocking));
+    HIPCHK(hipStreamSynchronize(sd.copy_st));                  // no copy of the previous owner still reads the slab
+    I.h_blind[slot].ensure(b->max_draws * 64);
+    sd.d.ensure(b->max_draws * 64);
+    while (sd.ev.size() < b->max_draws / BS::UP + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sd.ev.push_back(e); }
+    b->raw = I.h_blind[slot].as<uint8_t>();
+    b->device = device_; b->copy_st = sd.copy_st; b->d_raw = sd.d.as<uint8_t>(); b->ev = &sd.ev;
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
-    I.slab_owner[b->slot] = b;
+    I.slab_owner[slot] = b;
     I.blinds.push_back(b);
-    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); (void)keccak_impl(); I.chain->th = std::thread(Impl::ChainWorker::run, I.chain.get()); }
+    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); (void)keccak_impl(); }
+    while (I.chain->th.size() < I.chain_workers) I.chain->th.emplace_back(Impl::ChainWorker::run, I.chain.get());
     { std::lock_guard<std::mutex> lk(I.chain->mu); I.chain->pending.push_back(b); }
     I.chain->cv.notify_one();
+}
+void Engine::set_chain_workers(uint32_t n) {
+    if (n < 1 || n > 64) throw std::invalid_argument("chain workers: 1..64");
+    impl_->chain_shutdown();                                  // streams in flight are dropped; threads restart with the next begin
+    impl_->chain_workers = n;
 }
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
 int Engine::chain_cpu() const { return impl_->last_chain_cpu; }
@@ -1175,10 +1220,18 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         const uint64_t slab = 1u << 16;
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
-            if (bs) { while (bs->produced.load(std::memory_order_acquire) < i + cnt) std::this_thread::sleep_for(std::chrono::microseconds(40)); }     // drawn (or being drawn) by the chain worker
-            else rng.fill_draws64(raw + 64 * i, cnt);
-            HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
-            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
+            if (bs) {
+                // drawn (or being drawn) and uploaded block by block by the chain worker: wait until block i / UP has been handed to the copy
+                // stream, then make this stream wait for its event - no host copy, no copy on this stream
+                const uint64_t k = i / Impl::BlindStream::UP;
+                while (bs->uploaded_blocks.load(std::memory_order_acquire) <= k) std::this_thread::sleep_for(std::chrono::microseconds(40));
+                HIPCHK(hipStreamWaitEvent(st, (*bs->ev)[k], 0));
+                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt);
+            } else {
+                rng.fill_draws64(raw + 64 * i, cnt);
+                HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
+                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
+            }
             if (!merged && i + cnt < 2 * n) launch_pieces(i + cnt);
         }
     }

@@ -47,6 +47,8 @@ public:
     // transcript after the last commitment, v_blinding and the seed only.  prove() uses the stream iff all three still match, else discards it.
     void blinding_begin(const Transcript &after_commitments, const std::vector<Scalar> &v_blinding, const uint8_t seed[32], uint64_t max_multipliers);
     void blinding_cancel();
+    // threads of the context's chain worker: that many queued streams are drawn side by side, workers + 1 may be alive (default 1)
+    void set_chain_workers(uint32_t n);
     int chain_cpu() const;      // host core the chain worker last drew a stream on (-1: none yet); diagnostics for bench.py
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
     // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.

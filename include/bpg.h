@@ -176,13 +176,18 @@ bpg_status bpg_prover_instance(bpg_prover *p, bpg_r1cs_instance *out, const uint
  * Called once every commitment has been made, this starts that chain on a host thread while the caller keeps assembling constraints;
  * bpg_prover_prove / bpg_r1cs_prove(_resident) on the same context use the stream iff transcript state, blindings and rng_seed are still
  * the same and n <= max_multipliers, and silently draw afresh otherwise (another commitment, another seed, BPG_FLAG_EXPANDED_BLINDING).
- * Streams of one context are drawn ONE AT A TIME, in the order of the calls, by the context's chain worker (a single host thread); up to two
- * are alive (a third call retires the oldest), so a sequence of proofs can have the chain of proof i+1 drawn while the kernels of proof i
+ * Streams of one context are drawn in the order of the calls by the context's chain worker - ONE AT A TIME with its single default thread
+ * (bpg_ctx_set_chain_workers adds threads); workers + 1 are alive at most (one more call retires the oldest), so a sequence of proofs can have the chain of proof i+1 drawn while the kernels of proof i
  * run: call bpg_blinding_begin for proof i+1, then prove proof i.  max_multipliers sizes a pinned host buffer of 128 bytes per multiplier.
  * A deterministic rng_seed is for tests and benchmarks; production callers pass 32 fresh random bytes per proof (upstream: thread_rng()). */
 bpg_status bpg_prover_start_blinding(bpg_prover *p, const uint8_t rng_seed[32], uint64_t max_multipliers);
 bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[BPG_TRANSCRIPT_STATE_BYTES] /* after every "V" append */, uint64_t m,
                               const uint8_t *v_blinding /* m x 32 */, const uint8_t rng_seed[32], uint64_t max_multipliers);
+/* Threads of the context's chain worker (default 1, or BPG_CHAIN_WORKERS): with `workers` threads that many queued blinding streams are drawn
+ * side by side and workers + 1 may be alive, so a host that proves a SEQUENCE of independent proofs keeps bpg_blinding_begin `workers` proofs
+ * ahead of the proof it is proving and the GPU, not one host core's Keccak chain, sets the pace.  Streams in flight are dropped by the call.
+ * Each alive stream pins 128 bytes per multiplier of host memory. */
+bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers);
 int32_t bpg_chain_cpu(bpg_ctx *ctx);   /* diagnostics: host core the chain worker last ran on, -1 = no stream drawn yet */
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags,
                             uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);

@@ -684,6 +684,22 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     c2.blinding_begin(state, inst.v_blinding, seeds[0], 1 << 16)
     c2.blinding_begin(state, inst.v_blinding, seeds[1], 1 << 16)
     c2.close()
+    # several chain threads (bpg_ctx_set_chain_workers): workers + 1 streams alive, drawn side by side; bench.py's deep sequence
+    ctx.set_chain_workers(3)
+    try:
+        queued, got = 0, []
+        for k, s in enumerate(seeds):
+            while queued < len(seeds) and queued <= k + 3:
+                ctx.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                queued += 1
+            got.append(res.prove(state, inst.v_blinding, s, 0)[0])
+        assert got == alone
+        for s in seeds[:5]:                                      # a fifth begin retires the oldest of four
+            ctx.blinding_begin(state, inst.v_blinding, s, inst.n)
+        assert [res.prove(state, inst.v_blinding, s, 0)[0] for s in (seeds[4], seeds[0], seeds[2])] == [alone[4], alone[0], alone[2]]
+    finally:
+        ctx.set_chain_workers(1)                                 # drops what is still queued
+    assert res.prove(state, inst.v_blinding, seeds[3], 0)[0] == alone[3]
     res.free()
 
 
