@@ -46,8 +46,10 @@ def parse_args(argv=None):
     ap.add_argument("--baseline-leaves", type=int, default=512, help="leaves of the CPU-baseline tree (512 = the headline circuit itself, about 150 s on one core; "
                     "64 -> N = 2^17, about 17 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chain-workers", type=int, default=10, help="threads of each rank's chain worker = how many proofs ahead the sequence keeps its TranscriptRng "
+    ap.add_argument("--chain-workers", type=int, default=12, help="threads of each rank's chain worker = how many proofs ahead the sequence keeps its TranscriptRng "
                     "chains drawn (bpg_ctx_set_chain_workers): with ~10 the GPU sets the pace; 1 = one host thread, the chain of step i+1 under the kernels of step i")
+    ap.add_argument("--streams", type=int, default=2, help="proving streams per GPU for the headline: that many engine contexts (own HIP stream, proving thread and share of "
+                    "the chain workers) take the steps round-robin, so the host-side epilogues of one proof overlap the kernels of another")
     ap.add_argument("--no-prefetch", action="store_true", help="draw every chain inside its own prove call (round-1 behaviour): the GPU idles while the host draws")
     ap.add_argument("--batch", type=int, default=8, help="strong-scaling leg: this many independent proofs in total, sharded round-robin over the ranks (0 = skip)")
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
@@ -86,8 +88,8 @@ def _cpulist(text):
 
 
 def pin_near_gpu(torch, device_index):
-    """Restrict this rank (and the threads it creates later: the chain worker) to one hardware thread per physical core of the NUMA node
-    its GPU hangs off.  Returns a description for the JSON line; any failure leaves the affinity alone."""
+    """Restrict this rank (and the threads it creates later: chain workers, proving threads) to the CPUs of the NUMA node its GPU hangs off.
+    Returns a description for the JSON line; any failure leaves the affinity alone."""
     info = {"numa_node": None, "cpus_allowed": len(os.sched_getaffinity(0))}
     try:
         pr = torch.cuda.get_device_properties(device_index)
@@ -103,10 +105,13 @@ def pin_near_gpu(torch, device_index):
             sib = _cpulist(pathlib.Path("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read_text())
             if c == min(sib & cpus):
                 cores.add(c)
-        if len(cores) >= 2:
-            os.sched_setaffinity(0, cores)
-            info["cpus_allowed"] = len(cores)
-            info["pinned"] = "one thread per core of NUMA node %d" % node
+        if len(cpus) >= 2:
+            # every hardware thread of the node: the scheduler fills idle cores before it doubles up on one, and a rank's ~15 busy threads
+            # (chain workers, proving threads) plus the runtime's helpers must never be squeezed onto fewer cores than that
+            os.sched_setaffinity(0, cpus)
+            info["cpus_allowed"] = len(cpus)
+            info["cores_allowed"] = len(cores)
+            info["pinned"] = "the CPUs of NUMA node %d" % node
     except Exception as e:      # noqa: BLE001 - placement is an optimisation, never a reason to fail
         info["error"] = repr(e)
     return info
@@ -301,7 +306,9 @@ def run_rank(args):
     from bulletproofs_gadgets_amd import workloads
     from bulletproofs_gadgets_amd.batch import gather_proofs, shard_indices
     ctx = bpg.Context(device_index)
-    ctx.set_chain_workers(max(1, args.chain_workers))
+    n_streams = max(1, args.streams)
+    lane_workers = max(1, -(-max(1, args.chain_workers) // n_streams))       # chain threads per proving stream
+    ctx.set_chain_workers(lane_workers)
     t0 = time.perf_counter()
     a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=None if rank == 0 else rank)
     inst = a.prover.instance()
@@ -318,6 +325,12 @@ def run_rank(args):
             % (args.leaves, inst.n, a.gens_capacity, inst.q, inst.m, t_asm, t_gens, t_up))
     proof_len = bpg.lib().bpg_proof_size(inst.n, 0)
     prefetch = not args.no_prefetch
+    extra_lanes = []
+    for _ in range(n_streams - 1):
+        c2 = bpg.Context(device_index)
+        c2.set_chain_workers(lane_workers)
+        c2.gens_ensure(a.gens_capacity)
+        extra_lanes.append((c2, c2.upload(inst)))
 
     def seed_for(step):
         return bytes([rank & 0xff, step & 0xff, (step >> 8) & 0xff]) + bytes(29)
@@ -328,18 +341,49 @@ def run_rank(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    def prove_sequence(seeds, gather_each=True, ahead=None):
+    lanes = [(ctx, res)]                                     # proving streams of this rank: (context, resident circuit)
+
+    def prove_steps(seeds):
+        """The timed steps: seeds[p::P] go to proving stream p (own thread, context, HIP stream, chain workers); P = 1 is prove_sequence.
+        With several ranks the finished proofs of all steps are gathered once, at the end (inside the timed region)."""
+        P = len(lanes)
+        if P == 1:
+            outs = prove_sequence(seeds, gather_each=False)
+        else:
+            import threading
+            outs, errs = [None] * len(seeds), []
+
+            def work(p):
+                try:
+                    for k, o in enumerate(prove_sequence(seeds[p::P], gather_each=False, lane=p)):
+                        outs[p + k * P] = o
+                except Exception as e:      # noqa: BLE001
+                    errs.append(repr(e))
+            th = [threading.Thread(target=work, args=(p,)) for p in range(P)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise RuntimeError(errs[0])
+        if dist is not None:     # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather for the steps of the region)
+            proofs = gather_proofs({rank + world * i: o[0] for i, o in enumerate(outs)}, world * len(seeds), proof_len, dist, device=coll_device)
+            assert len(proofs) == world * len(seeds)
+        return outs
+
+    def prove_sequence(seeds, gather_each=True, ahead=None, lane=0):
         """Independent proofs, one after the other on this rank's context (one proving thread, one HIP stream).  With prefetch the chains of
         the next `ahead` proofs are queued on the chain worker before proof i is proved (bpg_blinding_begin: same bytes as drawing them inside
         prove); every chain of the sequence starts and ends inside it."""
-        ahead = args.chain_workers if ahead is None else ahead
+        c_, r_ = lanes[lane]
+        ahead = lane_workers if ahead is None else ahead
         outs = []
         queued = 0
         for i, s in enumerate(seeds):
             while prefetch and queued < len(seeds) and queued <= i + ahead:                  # streams i .. i + ahead alive (workers + 1 at most)
-                ctx.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                c_.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
                 queued += 1
-            out = res.prove(state, inst.v_blinding, s, 0)
+            out = r_.prove(state, inst.v_blinding, s, 0)
             if dist is not None and gather_each:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
                 proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
                 assert len(proofs) == world
@@ -373,14 +417,27 @@ def run_rank(args):
         return
 
     # ---- warm-up (not steps: the first proof of a context sizes its device workspaces), then EXACTLY `steps` timed proofs
-    prove_sequence([seed_for(2000 + i) for i in range(max(args.warmup, 1))])
-    ctx.profile_set(1)          # HIP events around the bucket sweep and the generator folds only (13 launches per proof)
+    lanes.extend(extra_lanes)
+    prove_steps([seed_for(2000 + i) for i in range(max(args.warmup, len(lanes)))])
+    for c_, _ in lanes:
+        c_.profile_set(1)       # HIP events around the bucket sweep and the generator folds only (11-13 launches per proof)
     barrier()
     t0 = time.perf_counter()
-    outs = prove_sequence([seed_for(i) for i in range(args.steps)])
+    outs = prove_steps([seed_for(i) for i in range(args.steps)])
     barrier()
     elapsed_local = time.perf_counter() - t0
-    prof = collect_profile()
+    prof = {}
+    for c_, _ in lanes:          # the streams' HIP-event records add up
+        rep = c_.profile_report()
+        c_.profile_set(0)
+        for name, v in rep.items():
+            acc = prof.setdefault(name, {k: 0 for k in v})
+            for k in v:
+                acc[k] += v[k]
+    del lanes[1:]                # the other legs use the first stream only
+    for c2, r2 in extra_lanes:
+        r2.free(); c2.close()
+    ctx.set_chain_workers(max(1, args.chain_workers))
     elapsed = allreduce(elapsed_local, dist.ReduceOp.MAX if dist else None)
     q_total = allreduce(float(inst.q), dist.ReduceOp.SUM if dist else None)
     chain_cpu = ctx.chain_cpu()
@@ -408,7 +465,7 @@ def run_rank(args):
         ctx.set_chain_workers(max(1, args.chain_workers))
         barrier()
         t0 = time.perf_counter()
-        prove_sequence([seed_for(3500 + i) for i in mine], gather_each=False)
+        prove_sequence([seed_for(3500 + i) for i in mine], gather_each=False, ahead=max(1, args.chain_workers))
         barrier()
         dtb_deep = allreduce(time.perf_counter() - t0, dist.ReduceOp.MAX if dist else None)
         batch_info = {"proofs": args.batch, "ranks": world, "proofs_per_rank": len(shard_indices(args.batch, 0, world)), "seconds": dtb,
@@ -558,10 +615,12 @@ def run_rank(args):
                                   % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                       "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
                       "chain": ("the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) of the next %d steps are drawn by the rank's "
-                                "chain worker on %d host threads while the kernels of step i run on one HIP stream; all %d chains start and end inside the "
-                                "timed region, so its first ~0.3 s are spent waiting for the first chains" % (args.chain_workers, args.chain_workers, args.steps))
+                                "chain workers on %d host threads while the kernels of the current steps run on %d HIP streams (steps dealt round-robin to that many "
+                                "engine contexts); all %d chains start and end inside the timed region, so its first ~0.3 s are spent waiting for the first "
+                                "chains" % (lane_workers * n_streams, lane_workers * n_streams, n_streams, args.steps))
                                if prefetch else "every chain is drawn inside its own prove call",
-                      "host_threads_per_gpu": {"chain_workers": args.chain_workers if prefetch else 0, "proving": 1},
+                      "host_threads_per_gpu": {"chain_workers": lane_workers * n_streams if prefetch else 0, "proving": n_streams},
+                      "proving_streams_per_gpu": n_streams,
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
            "single_stream": single, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
@@ -602,7 +661,7 @@ def run_rank(args):
         # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
         cb["gpu_over_cpu"] = out["value"] / cb["value"]
         cb["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * cb["value"])
-        cb["gpu_side_host_threads"] = (args.chain_workers if prefetch else 0) + 1
+        cb["gpu_side_host_threads"] = (lane_workers * n_streams if prefetch else 0) + n_streams
         if single is not None:
             cb["single_stream_over_cpu"] = single["value"] / cb["value"]      # one GPU + two host threads against one core
         out["cpu_baseline"] = cb
