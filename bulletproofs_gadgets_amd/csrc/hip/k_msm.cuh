@@ -150,9 +150,12 @@ __global__ void __launch_bounds__(256) k_msm_count1(MsmPlan P, const uint16_t *_
     for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     const uint16_t *D = dig + (size_t)win * total;
-    for (uint32_t g = g0 + threadIdx.x; g < g1 + 63u; g += blockDim.x) {          // whole waves take part in the ballot of msm_lds_take
-        const uint32_t mag = g < g1 ? (D[g] & 0x7fffu) : 0u;
-        (void)msm_lds_take(hist, mag ? (mag - 1u) >> P.fb : 0u, mag != 0u);
+    for (uint32_t gb = g0 + threadIdx.x; gb < g1 + 63u; gb += 4u * blockDim.x) {  // whole waves take part in the ballot of msm_lds_take; four loads in flight
+        uint32_t m4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t g = gb + u * blockDim.x; m4[u] = g < g1 ? (D[g] & 0x7fffu) : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) (void)msm_lds_take(hist, m4[u] ? (m4[u] - 1u) >> P.fb : 0u, m4[u] != 0u);
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) counts1[((size_t)mw * P.CB + b) * P.tmax + t] = hist[b];
@@ -172,9 +175,10 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
     // one pass of LDS atomics: the slot a term takes inside its coarse bin is kept (16 terms per thread, digit | slot << 16 in a register)
     uint32_t keep[MSM_TILE1_PER];
 #pragma unroll
+    for (uint32_t it = 0; it < MSM_TILE1_PER; it++) { const uint32_t g = g0 + it * 256u + threadIdx.x; keep[it] = g < g1 ? D[g] : 0u; }   // all loads first
+#pragma unroll
     for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
-        const uint32_t g = g0 + it * 256u + threadIdx.x;
-        const uint32_t d = g < g1 ? D[g] : 0u, mag = d & 0x7fffu;
+        const uint32_t d = keep[it], mag = d & 0x7fffu;
         const uint32_t slot = msm_lds_take(cnt, mag ? (mag - 1u) >> P.fb : 0u, mag != 0u);
         keep[it] = d | (slot << 16);
     }
@@ -224,10 +228,18 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
     for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) cnt[f] = 0;
     __syncthreads();
     const uint32_t fsh = 31u - P.fb, fmask = nf - 1u;
-    for (uint32_t e = s0 + threadIdx.x; e < s1 + 63u; e += blockDim.x) {
-        const bool on = e < s1;
-        const uint32_t slot = msm_lds_take(cnt, on ? (entries1[e] >> fsh) & fmask : 0u, on);
-        if (on && stash) slot16[e - s0] = (uint16_t)slot;
+    // four independent loads per thread and trip: a bin is a short stream (8 K entries), its latency, not its bytes, sets the pace
+    for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t e = e0 + u * blockDim.x; v[u] = e < s1 ? entries1[e] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t e = e0 + u * blockDim.x;
+            const bool on = e < s1;
+            const uint32_t slot = msm_lds_take(cnt, on ? (v[u] >> fsh) & fmask : 0u, on);
+            if (on && stash) slot16[e - s0] = (uint16_t)slot;
+        }
     }
     __syncthreads();
     if (threadIdx.x < 64) {                                  // exclusive prefix over nf <= 128 counters: two per lane
@@ -243,13 +255,20 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
     }
     __syncthreads();
     const uint32_t idxbits = 28u - P.fb, imask = (1u << idxbits) - 1u, chmask = (1u << P.lgCH) - 1u;
-    for (uint32_t e = s0 + threadIdx.x; e < s1 + 63u; e += blockDim.x) {
-        const bool on = e < s1;
-        const uint32_t v = on ? entries1[e] : 0u, f = (v >> fsh) & fmask;
-        const uint32_t pos = stash ? (on ? cur[f] + slot16[e - s0] : 0u) : msm_lds_take(cur, f, on);
-        if (on) {
-            entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
-            if ((pos & chmask) == 0u) chunk_key[pos >> P.lgCH] = k * nf + f;
+    for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
+        uint32_t vv[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t e = e0 + u * blockDim.x; vv[u] = e < s1 ? entries1[e] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const uint32_t e = e0 + u * blockDim.x;
+            const bool on = e < s1;
+            const uint32_t v = vv[u], f = (v >> fsh) & fmask;
+            const uint32_t pos = stash ? (on ? cur[f] + slot16[e - s0] : 0u) : msm_lds_take(cur, f, on);
+            if (on) {
+                entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
+                if ((pos & chmask) == 0u) chunk_key[pos >> P.lgCH] = k * nf + f;
+            }
         }
     }
 }
