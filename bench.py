@@ -518,16 +518,18 @@ def run_rank(args):
         kernels = collect_profile()
         gpu_ms_per_proof = sum(v["total_ms"] for v in kernels.values())
 
-    single = None
+    single, prof_isolated = None, None
     if not args.headline_only and prefetch and args.chain_workers > 1:
         # the round-1 / verdict figure for continuity: the same sequence with ONE chain drawn at a time (the chain of step i+1 under the kernels of step i)
         k1 = min(4, args.steps)
         ctx.set_chain_workers(1)                             # ONE host thread draws: queued chains run one after the other
+        ctx.profile_set(1)                                   # and ONE HIP stream: the kernels run undisturbed - the isolated figures of `roofline`
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s1 = prove_sequence([seed_for(i) for i in range(k1)], gather_each=False, ahead=1)
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t0) / k1
+        prof_isolated = collect_profile()
         ctx.set_chain_workers(max(1, args.chain_workers))
         assert [o[0] for o in s1] == [o[0] for o in outs[:k1]], "the same seeds gave other bytes with one chain at a time"
         single = {"steps": k1, "ms_per_step": dt1 * 1e3, "value": inst.q / dt1, "unit": "constraints/s",
@@ -571,8 +573,8 @@ def run_rank(args):
     first_group = min(fold_group, max(a.gens_capacity.bit_length() - 1 - tt_lg, 0))
     rocprof_name = {"k_fold_points_reg": "k_fold_points_reg<%d>" % ((1 << first_group) - 1)}
 
-    def kernel_roofline(name):
-        k = prof[name]
+    def kernel_roofline(name, table=None):
+        k = (table or prof)[name]
         secs = k["total_ms"] * 1e-3
         launches = max(k["count"], 1)
         t = traffic_tab.get(rocprof_name.get(name, name))
@@ -602,6 +604,13 @@ def run_rank(args):
                     "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
                             "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv)",
                     "valu": dom["valu"], "whole_proof": whole, "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
+        if n_streams > 1:
+            roofline["note"] += ("; %d proving streams share the GPU inside the timed steps, so a launch there overlaps kernels of another proof and lasts "
+                                 "longer than it does alone: `isolated` repeats the figures from the single-stream leg" % n_streams)
+        if prof_isolated and ranked[0] in prof_isolated:
+            iso = kernel_roofline(ranked[0], prof_isolated)
+            roofline["isolated"] = {k: iso[k] for k in ("kernel", "launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu")}
+            roofline["isolated"]["other_kernels"] = [kernel_roofline(n, prof_isolated) for n in ranked[1:] if n in prof_isolated]
     else:
         roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None, "whole_proof": whole,
                     "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}

@@ -3,7 +3,8 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 calib stats pmc'      and      gpurun --timeout 900 -- 'bash tools/profile_round.sh r02 bench'
 # stages (any subset, in this order):
 #   calib  FETCH_SIZE calibration on a known byte count (tools/calib/gather_calib.hip)          -> gpurun_out/<tag>_fetch_calibration.json
-#   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only and --in-flight-only    -> gpurun_out/<tag>_stats/, <tag>_stats_inflight/ (+ the bench lines under the profiler)
+#   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only (as timed: two streams), of the same with one stream and
+#          one chain thread (kernels alone on the GPU), and of --in-flight-only  -> gpurun_out/<tag>_stats/, <tag>_stats_single/, <tag>_stats_inflight/
 #   pmc    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only                -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/, <tag>_pmc_traffic.json
 #   bench  the default bench line exactly as the driver runs it (cpu_baseline, throughput, batch) -> gpurun_out/<tag>_bench_plain.json
 # rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
@@ -25,16 +26,19 @@ if has calib; then
     echo "calib done"
 fi
 if has stats; then
-    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 5 --warmup 2 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err") || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 20 --warmup 5 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err") || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
     echo "stats done"
+    # the same kernels alone on the GPU: one proving stream, one chain thread (the `isolated` figures of the bench line, the round-1 command)
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_single" -o "$tag" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 5 --warmup 2 > "$out/${tag}_bench_single_under_rocprof.json" 2> "$out/${tag}_stats_single.err") || { echo "single-stream stats pass failed"; tail -5 "$out/${tag}_stats_single.err"; exit 1; }
+    echo "single-stream stats done"
     # the concurrent mix of the throughput leg: 12 proofs in flight on 12 streams, kernels of different proofs share the CUs
     (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight 12 --steps 6 > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
     echo "in-flight stats done"
 fi
 if has pmc; then
-    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err") || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmc_fetch" -o "$tag" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_fetch.err") || { echo "fetch pass failed"; tail -5 "$out/${tag}_pmc_fetch.err"; exit 1; }
     echo "fetch done"
-    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err") || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
+    (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err") || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
     echo "write done"
     calib="$out/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/${tag}_fetch_calibration.json"
     python3 "$root/tools/pmc_summarize.py" "$(csv "$out/${tag}_pmc_fetch" counter_collection.csv)" "$(csv "$out/${tag}_pmc_write" counter_collection.csv)" "$calib" "$out/${tag}_pmc_traffic.json" || exit 1
