@@ -271,3 +271,34 @@ def test_python_binding_checks_buffer_lengths_and_defaults_to_fresh_seeds():
         params = inspect.signature(fn).parameters
         name = "rng_seed" if "rng_seed" in params else "seed"
         assert params[name].default is None, fn.__qualname__
+
+
+def test_profile_tooling_on_synthetic_counter_files(tmp_path):
+    """tools/calib/fetch_factor.py and tools/pmc_summarize.py on hand-made rocprofv3 CSVs: the FETCH_SIZE factor is known bytes / counter bytes,
+    gather kernels get the calibrated factor, everything else the streaming one, and the result carries the hash of the kernel sources
+    (bench.py quotes `traffic` only when that hash is the one of the sources it runs)."""
+    import json, subprocess, sys
+    root = pathlib.Path(__file__).resolve().parent.parent
+    known = {"table_bytes": 1000, "rows_gathered": 10, "known_bytes": {"k_calib_stream": 2048.0, "k_calib_gather<6>": 960.0, "k_calib_gather<8>": 960.0},
+             "ms": {}, "GBps": {}}
+    (tmp_path / "known.json").write_text(json.dumps(known) + "\n")
+    hdr = "Kernel_Name,Counter_Name,Counter_Value\n"
+    (tmp_path / "calib.csv").write_text(hdr + 'k_calib_stream(uint4 const*),FETCH_SIZE,1.0\n"void k_calib_gather<6>(uint4 const*)",FETCH_SIZE,1.0\n'
+                                        '"void k_calib_gather<8>(uint4 const*)",FETCH_SIZE,0.5\n')
+    subprocess.check_call([sys.executable, str(root / "tools/calib/fetch_factor.py"), str(tmp_path / "known.json"), str(tmp_path / "calib.csv"), str(tmp_path / "calib.json")],
+                          stdout=subprocess.DEVNULL)
+    cal = json.loads((tmp_path / "calib.json").read_text())["summary"]
+    assert cal["stream_factor"] == 2.0 and cal["gather96_factor"] == 960.0 / 1024.0
+    (tmp_path / "fetch.csv").write_text(hdr + "bpg::k_bucket_chunks(bpg::MsmSegs),FETCH_SIZE,100\nbpg::k_bucket_chunks(bpg::MsmSegs),FETCH_SIZE,300\nbpg::k_poly_t(x),FETCH_SIZE,10\n")
+    (tmp_path / "write.csv").write_text(hdr + "bpg::k_bucket_chunks(bpg::MsmSegs),WRITE_SIZE,4\nbpg::k_bucket_chunks(bpg::MsmSegs),WRITE_SIZE,4\nbpg::k_poly_t(x),WRITE_SIZE,2\n")
+    subprocess.check_call([sys.executable, str(root / "tools/pmc_summarize.py"), str(tmp_path / "fetch.csv"), str(tmp_path / "write.csv"), str(tmp_path / "calib.json"),
+                           str(tmp_path / "traffic.json")], stdout=subprocess.DEVNULL)
+    t = json.loads((tmp_path / "traffic.json").read_text())
+    sys.path.insert(0, str(root))
+    import bench
+    assert t["_meta"]["source_hash"] == bench.source_hash() and len(t["_meta"]["source_hash"]) == 16
+    sweep, poly = t["k_bucket_chunks"], t["k_poly_t"]
+    assert sweep["launches"] == 2 and sweep["fetch_factor"] == 960.0 / 1024.0 and poly["fetch_factor"] == 2.0
+    assert abs(sweep["hbm_bytes_per_launch"] - (200 * 1024 * 960.0 / 1024.0 + 4 * 1024)) < 1e-6
+    assert abs(poly["hbm_bytes_per_launch"] - (10 * 1024 * 2.0 + 2 * 1024)) < 1e-6
+    assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
