@@ -342,6 +342,7 @@ def run_rank(args):
         torch.cuda.synchronize()
 
     lanes = [(ctx, res)]                                     # proving streams of this rank: (context, resident circuit)
+    done_at = []                                             # completion time of every proof of the current region (list.append is atomic)
 
     def prove_steps(seeds):
         """The timed steps: seeds[p::P] go to proving stream p (own thread, context, HIP stream, chain workers); P = 1 is prove_sequence.
@@ -384,6 +385,7 @@ def run_rank(args):
                 c_.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
                 queued += 1
             out = r_.prove(state, inst.v_blinding, s, 0)
+            done_at.append(time.perf_counter())
             if dist is not None and gather_each:   # the only data that crosses xGMI: the finished proof bytes (one RCCL all_gather per step)
                 proofs = gather_proofs({rank: out[0]}, world, proof_len, dist, device=coll_device)
                 assert len(proofs) == world
@@ -422,10 +424,19 @@ def run_rank(args):
     for c_, _ in lanes:
         c_.profile_set(1)       # HIP events around the bucket sweep and the generator folds only (11-13 launches per proof)
     barrier()
+    del done_at[:]
     t0 = time.perf_counter()
     outs = prove_steps([seed_for(i) for i in range(args.steps)])
     barrier()
     elapsed_local = time.perf_counter() - t0
+    # the same timed steps seen from their completion times: the region opens with every chain still to be drawn (~0.3 s before the first
+    # proof can finish), after that the GPU sets the pace; `steady_state` is the rate between the first and the last completion
+    done = sorted(done_at)
+    steady = None
+    if len(done) > 2 and done[-1] > done[0]:
+        steady = {"first_proof_done_ms": (done[0] - t0) * 1e3, "ms_per_step": (done[-1] - done[0]) / (len(done) - 1) * 1e3,
+                  "note": "rank 0, inside the timed steps: time from the first to the last completion / (steps - 1); `value` is steps / the whole region"}
+        steady["value"] = inst.q * world / (steady["ms_per_step"] * 1e-3)
     prof = {}
     for c_, _ in lanes:          # the streams' HIP-event records add up
         rep = c_.profile_report()
@@ -634,6 +645,13 @@ def run_rank(args):
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
            "single_stream": single, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
            "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
+    if steady is not None:
+        per_gpu_ms = steady["ms_per_step"]
+        steady["valu"] = {"unit": "field-mult/s", "achieved": fm_per_proof * 1e3 / per_gpu_ms, "peak": peak_fm,
+                          "frac": fm_per_proof * 1e3 / per_gpu_ms / peak_fm if peak_fm else None,
+                          "counted": "field multiplications of the bucket sweeps and the generator folds only (%.3g per proof)" % fm_per_proof}
+        steady["hbm"] = {"achieved": b_alg * 1e3 / per_gpu_ms / 1e9, "unit": "GB/s", "frac": b_alg * 1e3 / per_gpu_ms / 8e12}
+        out["steady_state"] = steady
     if gpu_ms_per_proof is not None:
         out["gpu_busy"] = {"kernel_ms_per_proof": gpu_ms_per_proof, "fraction_of_step": gpu_ms_per_proof / (t_step * 1e3),
                            "note": "sum of the HIP-event durations of every kernel of one (untimed) proof / ms_per_step"}
