@@ -11,6 +11,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -52,6 +53,20 @@ struct PinBuf {
     void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
 };
+
+// Generator tables of one (device, capacity), shared by every context of the process on that device: the affine-Niels table [G | H] and, built on
+// first use, the odd multiples for the width-w NAF fold (one set per w).  Immutable once published, so contexts on different streams read them
+// freely; two proving streams then gather from ONE 201 MB table that the Infinity Cache holds, instead of two that evict each other.  A context that
+// needs a larger capacity moves to another generation; a generation is freed with its last context.
+struct SharedTables {
+    int device = 0; uint64_t cap = 0;
+    DevBuf gens;
+    std::mutex m;                                   // guards odd (construction on first use)
+    std::map<uint32_t, DevBuf> odd;                 // w -> [(2^(w-2) - 1)][2*cap] Niels points
+    ~SharedTables() { (void)hipSetDevice(device); gens.release(); for (auto &kv : odd) kv.second.release(); }
+};
+static std::mutex g_tables_mutex;                   // held across a derivation: contexts created side by side derive once
+static std::map<std::pair<int, uint64_t>, std::weak_ptr<SharedTables>> g_tables;
 
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -173,7 +188,9 @@ struct Engine::Impl {
         prof_open.clear();
     }
     void prof_reset() { prof_collect(); for (int i = 0; i < KID_COUNT; i++) { prof_ms[i] = 0; prof_count[i] = 0; prof_alg_bytes[i] = prof_act_bytes[i] = prof_fm[i] = 0; } }
-    DevBuf gens, bases, scratch_ext, comp, small_in, small_sc;
+    std::shared_ptr<SharedTables> shared;       // the generation of generator tables this context works on
+    DevBuf gens;                                // view of shared->gens (not owned)
+    DevBuf bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
     DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, chunk_key, digits, entries1, starts1;
     uint32_t sort_levels = 2;       // 2 = two-level sort (digits -> coarse partition -> fine sort per bin), 1 = one-level tile sort (BPG_MSM_SORT)
@@ -201,22 +218,26 @@ struct Engine::Impl {
     PinBuf h_naf;
     // odd multiples 3P, 5P, .. (2^(w-1) - 1)P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf);
     // built on first use for the current generator tables, rebuilt when those are extended
-    DevBuf gens_odd; uint32_t fold_wnaf = 6; uint32_t odd_w = 0; uint64_t odd_cap = 0; const void *odd_gens = nullptr;
+    DevBuf gens_odd;                 // view of shared->odd[fold_wnaf] (not owned)
+    uint32_t fold_wnaf = 8;
     void odd_ensure() {
-        if (odd_w == fold_wnaf && odd_cap == gens_cap && odd_gens == gens.p) return;
+        std::lock_guard<std::mutex> lk(shared->m);
+        auto it = shared->odd.find(fold_wnaf);
+        if (it != shared->odd.end()) { gens_odd = it->second; return; }
         const uint32_t nm = (1u << (fold_wnaf - 2)) - 1u, cnt = (uint32_t)(2 * gens_cap);
-        gens_odd.ensure((size_t)nm * cnt * sizeof(ge_niels));
+        DevBuf odd; odd.ensure((size_t)nm * cnt * sizeof(ge_niels));
         scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
         DevBuf dbl; dbl.ensure((size_t)cnt * sizeof(ge_ext));
         BPG_LAUNCH((*this), k_odd_start, dim3(cdiv(cnt, 256)), dim3(256), gens.as<ge_niels>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
         for (uint32_t m = 1; m <= nm; m++) {
             if (m > 1) BPG_LAUNCH((*this), k_odd_step, dim3(cdiv(cnt, 256)), dim3(256), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
-            BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), gens_odd.as<ge_niels>() + (size_t)(m - 1) * cnt, cnt);
+            BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), odd.as<ge_niels>() + (size_t)(m - 1) * cnt, cnt);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         dbl.release();
-        odd_w = fold_wnaf; odd_cap = gens_cap; odd_gens = gens.p;
+        shared->odd[fold_wnaf] = odd;
+        gens_odd = odd;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
@@ -309,7 +330,8 @@ struct Engine::Impl {
     uint64_t gens_cap = 0;
     // BPG_GENS_CACHE_DIR (see gens_cache_path): load = read + checksum + upload + compare 2 x 64 sampled points with points derived afresh from
     // the SHAKE256 stream (k_gens_derive on 128 generators); anything that does not agree falls back to the full derivation
-    bool gens_load_cached(const std::string &path, uint64_t cap);
+    bool gens_load_cached(const std::string &path, uint64_t cap, DevBuf &out);
+    void adopt(const std::shared_ptr<SharedTables> &sp) { shared = sp; gens = sp->gens; gens_cap = sp->cap; gens_odd = DevBuf(); }
     void gens_store_cached(const std::string &path, uint64_t cap);
 
     // An MSM runs on the GPU down to its W window sums per result; those (W x 128 B) travel to a pinned slot and the serial recombination
@@ -366,7 +388,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 7)) impl_->fold_wnaf = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
@@ -392,12 +414,13 @@ Engine::~Engine() {
     impl_->chain_shutdown();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(impl_->st);
-    DevBuf *bufs[] = {&impl_->gens, &impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
+    DevBuf *bufs[] = {&impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->gens_odd, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
+    impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
     for (auto &sd : impl_->slab_dev) {
         if (sd->copy_st) { (void)hipStreamSynchronize(sd->copy_st); (void)hipStreamDestroy(sd->copy_st); }
@@ -468,8 +491,24 @@ void Engine::gens_ensure(uint64_t capacity) {
     // GeneratorsChain: SHAKE256("GeneratorsChain" || 'G'|'H' || u32le(party = 0)), 64 bytes per generator (host squeeze,
     // a serial XOF), then 2*capacity Elligator maps + one batched normalisation on the device.
     const uint64_t cap = capacity;
+    std::lock_guard<std::mutex> tables_lock(g_tables_mutex);
+    const char *share_env = std::getenv("BPG_GENS_SHARE");              // 0: this context derives (or loads) and keeps tables of its own
+    const bool share = !share_env || std::atoi(share_env) != 0;
+    if (share) {   // another context of this device already holds tables of this capacity: adopt them
+        auto it = g_tables.find({device_, cap});
+        if (it != g_tables.end()) {
+            if (std::shared_ptr<SharedTables> sp = it->second.lock()) { I.adopt(sp); gens_cap_ = cap; return; }
+            g_tables.erase(it);
+        }
+    }
+    auto publish = [&](DevBuf fresh) {
+        auto sp = std::make_shared<SharedTables>();
+        sp->device = device_; sp->cap = cap; sp->gens = fresh;
+        if (share) g_tables[{device_, cap}] = sp;
+        I.adopt(sp); gens_cap_ = cap;
+    };
     const std::string cache_file = gens_cache_path(cap);
-    if (!cache_file.empty() && I.gens_load_cached(cache_file, cap)) { gens_cap_ = I.gens_cap = cap; return; }
+    if (!cache_file.empty()) { DevBuf loaded; if (I.gens_load_cached(cache_file, cap, loaded)) { publish(loaded); return; } }
     I.h_raw.ensure(2 * cap * 64);
     {   // the two chains are independent XOF streams: squeeze them on two threads; the streams are prefixes of one another across
         // capacities, so a process-wide cache keeps the longest one squeezed so far (contexts of a batch share it)
@@ -503,13 +542,11 @@ void Engine::gens_ensure(uint64_t capacity) {
     BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), fresh.as<ge_niels>(), cnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(I.st));
-    I.gens.release();
-    I.gens = fresh;
-    gens_cap_ = I.gens_cap = cap;
+    publish(fresh);
     if (!cache_file.empty()) I.gens_store_cached(cache_file, cap);
 }
 
-bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap) {
+bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap, DevBuf &out) {
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
     const size_t bytes = (size_t)2 * cap * sizeof(ge_niels);
@@ -546,8 +583,7 @@ bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap) {
     HIPCHK(hipStreamSynchronize(st));
     host.release(); smp.release();
     if (std::memcmp(enc.data(), enc.data() + (size_t)2 * SAMPLE * 32, (size_t)2 * SAMPLE * 32) != 0) { fresh.release(); return false; }
-    gens.release();
-    gens = fresh;
+    out = fresh;
     return true;
 }
 void Engine::Impl::gens_store_cached(const std::string &path, uint64_t cap) {

@@ -395,7 +395,7 @@ def test_skewed_witness_distributions(ctx):
 @pytest.mark.parametrize("tt_lg,group,split,wnaf,quad", [
     (0, 1, 1, 6, 1), (0, 2, 1, 6, 1), (0, 3, 1, 6, 1), (0, 5, 1, 6, 1), (3, 1, 1, 6, 1), (3, 2, 1, 6, 1), (3, 3, 1, 6, 1),
     (5, 4, 1, 6, 1), (8, 2, 1, 6, 1), (9, 5, 1, 6, 1), (11, 3, 1, 6, 1), (0, 2, 0, 0, 1), (0, 3, 0, 0, 1), (3, 4, 0, 0, 1),
-    (0, 4, 1, 6, 1), (0, 2, 0, 6, 1), (0, 3, 0, 6, 1), (3, 4, 0, 5, 1), (0, 3, 0, 4, 1), (0, 1, 0, 3, 1), (0, 5, 0, 7, 1),
+    (0, 4, 1, 6, 1), (0, 2, 0, 6, 1), (0, 3, 0, 6, 1), (3, 4, 0, 5, 1), (0, 3, 0, 4, 1), (0, 1, 0, 3, 1), (0, 5, 0, 7, 1), (0, 3, 0, 8, 1), (0, 2, 1, 8, 1),
     (6, 3, 0, 6, 1), (0, 3, 1, 6, 0), (3, 2, 1, 6, 0), (0, 2, 1, 6, 0), (5, 4, 1, 6, 0), (0, 4, 1, 0, 0)])
 def test_ipa_schedules_give_identical_proofs(tt_lg, group, split, wnaf, quad, monkeypatch):
     """The inner-product argument can be scheduled in many ways - generator folds grouped over `group` rounds, generators frozen
@@ -703,12 +703,57 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     res.free()
 
 
+def test_contexts_of_one_device_share_generator_tables(monkeypatch):
+    """Contexts of one device share their generator tables and the odd multiples of the width-w NAF fold (engine.hip SharedTables): two contexts prove
+    side by side on their own streams from the same tables, the tables outlive the context that derived them, and a context that asks for a
+    larger capacity moves to a new generation without disturbing the others.  Same bytes as the oracle throughout."""
+    import threading
+    monkeypatch.setenv("BPG_TT_LG", "0")
+    monkeypatch.setenv("BPG_FOLD_SPLIT", "0")            # the width-w NAF fold at this small size
+    monkeypatch.setenv("BPG_FOLD_GROUP", "3")
+    c1, c2 = bpg.Context(0), bpg.Context(0)
+    a = workloads.mimc_preimage(c1, nbytes=20, seed=3, label=b"MiMCHash")
+    inst = a.prover.instance()
+    og = O.Gens(1024)
+    seeds = [bytes([k]) * 32 for k in range(4)]
+    want = []
+    for s in seeds:
+        rc, w, _ = O.prove(og, a.transcript.state, to_oracle(inst), inst.v_blinding, s, O.FLAG_FAST_MSM)
+        assert rc == 0
+        want.append(w)
+    c1.gens_ensure(1024); c2.gens_ensure(1024)
+    assert c1.gens_export(0, 8) == c2.gens_export(0, 8)
+    r1, r2 = c1.upload(inst), c2.upload(inst)
+    got, errs = {}, []
+
+    def run(tag, r):
+        try:
+            got[tag] = [r.prove(a.transcript.state, inst.v_blinding, s, 0)[0] for s in seeds]
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=run, args=(1, r1)), threading.Thread(target=run, args=(2, r2))]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs and got[1] == want and got[2] == want
+    r1.free(); c1.close()                                  # the deriving context goes away; c2 keeps the tables alive
+    assert r2.prove(a.transcript.state, inst.v_blinding, seeds[1], 0)[0] == want[1]
+    c3 = bpg.Context(0)
+    c3.gens_ensure(4096)                                   # a new generation beside the one c2 uses
+    assert c3.gens_export(0, 1024) == c2.gens_export(0, 1024)      # the chains are prefixes of one another
+    c2.gens_ensure(4096)                                   # c2 moves over (adopts c3's tables); its resident circuit still proves
+    assert r2.prove(a.transcript.state, inst.v_blinding, seeds[2], 0)[0] == want[2]
+    r2.free(); c2.close(); c3.close()
+
+
 def test_generator_cache_on_disk(tmp_path, monkeypatch):
     """BPG_GENS_CACHE_DIR: the table written by one context is what a second one loads (same exported generators, same
     proof bytes); a file with a flipped byte (checksum), a truncated file, a wrong capacity in the header, and a file whose FIRST point was
     replaced with a consistent checksum (sample comparison against freshly derived generators) are all ignored and the table is re-derived."""
     import struct
     monkeypatch.setenv("BPG_GENS_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("BPG_GENS_SHARE", "0")              # a live context with tables of this capacity would otherwise be adopted before the file is looked at
     cap = 4096
     path = tmp_path / ("gens_%d.bpg" % cap)
 

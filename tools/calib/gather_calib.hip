@@ -37,8 +37,11 @@ __global__ void __launch_bounds__(256) k_calib_gather(const uint4 *__restrict__ 
     out[tid] = acc;
 }
 
-int main() {
-    const uint32_t nrows = 1u << 21;                                // 2 * 2^20 points
+int main(int argc, char **argv) {
+    // argv[1] = table size in units of the 2^21-row generator table (default 1; 17 = the 3.4 GB a pre-shifted table per window would take:
+    // the gather rate once the table no longer fits the 256 MB Infinity Cache)
+    const uint32_t mult = argc > 1 ? (uint32_t)std::atoi(argv[1]) : 1u;
+    const uint32_t nrows = (mult ? mult : 1u) << 21;                // 2 * 2^20 points per unit
     const size_t bytes96 = (size_t)nrows * 96, bytes128 = (size_t)nrows * 128;
     uint4 *t96, *t128; uint32_t *out;
     const uint32_t blocks = 256 * 32, threads = 256, iters = 8;     // 2^21 lanes * 8 rows = 16.8 M rows
