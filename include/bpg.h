@@ -75,7 +75,8 @@ bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out);
 void bpg_ctx_destroy(bpg_ctx *ctx);
 bpg_status bpg_pedersen_bases(bpg_ctx *ctx, uint8_t B[32], uint8_t B_blinding[32]);
 
-/* replaces BulletproofGens::new(capacity, 1)                     (reference src/bin/prover.rs:92); tables stay in HBM */
+/* replaces BulletproofGens::new(capacity, 1)                     (reference src/bin/prover.rs:92); tables stay in HBM.
+   Contexts of one process on one device share the tables of a capacity (derived once, immutable, freed with the last context using them). */
 bpg_status bpg_gens_ensure(bpg_ctx *ctx, uint64_t capacity);
 bpg_status bpg_gens_export(bpg_ctx *ctx, uint64_t first, uint64_t count, uint8_t *G_out, uint8_t *H_out);
 
