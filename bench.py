@@ -46,10 +46,12 @@ def parse_args(argv=None):
     ap.add_argument("--baseline-leaves", type=int, default=512, help="leaves of the CPU-baseline tree (512 = the headline circuit itself, about 150 s on one core; "
                     "64 -> N = 2^17, about 17 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--chain-workers", type=int, default=12, help="threads of each rank's chain worker = how many proofs ahead the sequence keeps its TranscriptRng "
-                    "chains drawn (bpg_ctx_set_chain_workers): with ~10 the GPU sets the pace; 1 = one host thread, the chain of step i+1 under the kernels of step i")
-    ap.add_argument("--streams", type=int, default=2, help="proving streams per GPU for the headline: that many engine contexts (own HIP stream, proving thread and share of "
-                    "the chain workers) take the steps round-robin, so the host-side epilogues of one proof overlap the kernels of another")
+    ap.add_argument("--chain-workers", type=int, default=14, help="chain threads per rank (bpg_ctx_set_chain_workers, shared out over the proving streams) = how many "
+                    "TranscriptRng chains are drawn side by side; sized for the ~16 cores a GPU has to itself on an 8-GPU host; 1 = one host thread, the chain of "
+                    "step i+1 under the kernels of step i")
+    ap.add_argument("--streams", type=int, default=14, help="proving streams per GPU for the headline (at most one per step): that many engine contexts (own HIP stream, "
+                    "proving thread, share of the chain workers; generator tables shared) take the steps round-robin. With one chain thread per stream every proof "
+                    "runs A_I, A_O and most of S under its own chain, so the GPU works through the 0.3 s the first chains take")
     ap.add_argument("--no-prefetch", action="store_true", help="draw every chain inside its own prove call (round-1 behaviour): the GPU idles while the host draws")
     ap.add_argument("--batch", type=int, default=8, help="strong-scaling leg: this many independent proofs in total, sharded round-robin over the ranks (0 = skip)")
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
@@ -270,6 +272,9 @@ def run_rank(args):
     # the throughput leg runs a dozen engine streams: 8 hardware queues instead of the runtime's default 4 measured 8 % more proofs/s
     # (tools/diag/exp1.sh); read by the HIP runtime at initialisation, so set before torch / the library load it
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # proving threads sleep in their stream waits instead of spinning (hipDeviceScheduleBlockingSync, read by the engine at context creation):
+    # with a dozen of them beside a dozen chain threads the spinning costs the chains their cores (measured: 51 -> 54.5 M constraints/s at 14 streams)
+    os.environ.setdefault("BPG_SYNC_BLOCKING", "1")
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,7 +311,7 @@ def run_rank(args):
     from bulletproofs_gadgets_amd import workloads
     from bulletproofs_gadgets_amd.batch import gather_proofs, shard_indices
     ctx = bpg.Context(device_index)
-    n_streams = max(1, args.streams)
+    n_streams = max(1, min(args.streams, args.steps))         # more streams than steps would only allocate
     lane_workers = max(1, -(-max(1, args.chain_workers) // n_streams))       # chain threads per proving stream
     ctx.set_chain_workers(lane_workers)
     t0 = time.perf_counter()
@@ -429,14 +434,13 @@ def run_rank(args):
     outs = prove_steps([seed_for(i) for i in range(args.steps)])
     barrier()
     elapsed_local = time.perf_counter() - t0
-    # the same timed steps seen from their completion times: the region opens with every chain still to be drawn (~0.3 s before the first
-    # proof can finish), after that the GPU sets the pace; `steady_state` is the rate between the first and the last completion
+    # the same timed steps seen from their completion times (rank 0): the region opens with every chain still to be drawn, so nothing can
+    # finish for ~0.3 s; what the GPU does meanwhile (A_I, A_O, S under the chains) and how the completions bunch afterwards is the timeline
     done = sorted(done_at)
-    steady = None
-    if len(done) > 2 and done[-1] > done[0]:
-        steady = {"first_proof_done_ms": (done[0] - t0) * 1e3, "ms_per_step": (done[-1] - done[0]) / (len(done) - 1) * 1e3,
-                  "note": "rank 0, inside the timed steps: time from the first to the last completion / (steps - 1); `value` is steps / the whole region"}
-        steady["value"] = inst.q * world / (steady["ms_per_step"] * 1e-3)
+    completions = None
+    if done:
+        completions = {"first_ms": (done[0] - t0) * 1e3, "median_ms": (done[len(done) // 2] - t0) * 1e3, "last_ms": (done[-1] - t0) * 1e3,
+                       "note": "rank 0: when the first, the median and the last of the timed proofs finished, from the start of the timed region"}
     prof = {}
     for c_, _ in lanes:          # the streams' HIP-event records add up
         rep = c_.profile_report()
@@ -615,13 +619,25 @@ def run_rank(args):
                     "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
                             "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv)",
                     "valu": dom["valu"], "whole_proof": whole, "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
-        if n_streams > 1:
-            roofline["note"] += ("; %d proving streams share the GPU inside the timed steps, so a launch there overlaps kernels of another proof and lasts "
-                                 "longer than it does alone: `isolated` repeats the figures from the single-stream leg" % n_streams)
-        if prof_isolated and ranked[0] in prof_isolated:
+        if n_streams > 1 and prof_isolated and ranked[0] in prof_isolated:
+            # with several proving streams a launch inside the timed steps shares the CUs with kernels of other proofs, and its duration says how
+            # the GPU was shared, not how good the kernel is (14 streams: 2.4 - 3.1 ms per sweep from run to run, 0.97 ms alone).  The headline
+            # figures of `roofline` are therefore the kernel ALONE on the GPU - HIP events in the single-stream leg of this same run, the
+            # command whose rocprofv3 --stats summary is profiles/*_kernel_stats_single_stream.csv - and the shared figures follow beside them
+            shared = {k: roofline[k] for k in ("launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu", "other_kernels")}
+            shared["note"] = ("the same kernel inside the timed steps, where %d proving streams share the GPU (HIP events on each stream, summed); "
+                              "rocprofv3 --stats of the headline command: profiles/*_rocprof_kernel_stats.csv" % n_streams)
             iso = kernel_roofline(ranked[0], prof_isolated)
-            roofline["isolated"] = {k: iso[k] for k in ("kernel", "launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu")}
-            roofline["isolated"]["other_kernels"] = [kernel_roofline(n, prof_isolated) for n in ranked[1:] if n in prof_isolated]
+            for k in ("launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu"):
+                roofline[k] = iso[k]
+            roofline["other_kernels"] = [kernel_roofline(n, prof_isolated) for n in ranked[1:] if n in prof_isolated]
+            roofline["measured"] = ("kernel alone on the GPU: HIP events on the engine's stream in the single-stream leg of this run (one proving stream, one "
+                                    "chain thread; rocprofv3 --stats of that command: profiles/*_kernel_stats_single_stream.csv). `timed_steps_shared` = the "
+                                    "same kernel inside the timed steps of the headline")
+            roofline["timed_steps_shared"] = shared
+        elif n_streams > 1:
+            roofline["note"] += ("; %d proving streams share the GPU inside the timed steps, so a launch there overlaps kernels of another proof and lasts "
+                                 "longer than it does alone (run without --headline-only for the kernel alone)" % n_streams)
     else:
         roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None, "whole_proof": whole,
                     "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
@@ -634,10 +650,11 @@ def run_rank(args):
            "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
                                   % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                       "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
-                      "chain": ("the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) of the next %d steps are drawn by the rank's "
-                                "chain workers on %d host threads while the kernels of the current steps run on %d HIP streams (steps dealt round-robin to that many "
-                                "engine contexts); all %d chains start and end inside the timed region, so its first ~0.3 s are spent waiting for the first "
-                                "chains" % (lane_workers * n_streams, lane_workers * n_streams, n_streams, args.steps))
+                      "chain": ("the steps are dealt round-robin to %d proving streams per GPU (engine contexts: own HIP stream and proving thread, generator tables "
+                                "shared); the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) are drawn by %d chain threads, "
+                                "%d per stream, each stream keeping the chain of its next step queued. All %d chains start and end inside the timed region: "
+                                "nothing can finish in its first ~0.3 s, during which the streams run A_I, A_O and most of S under their chains"
+                                % (n_streams, lane_workers * n_streams, lane_workers, args.steps))
                                if prefetch else "every chain is drawn inside its own prove call",
                       "host_threads_per_gpu": {"chain_workers": lane_workers * n_streams if prefetch else 0, "proving": n_streams},
                       "proving_streams_per_gpu": n_streams,
@@ -645,13 +662,8 @@ def run_rank(args):
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
            "single_stream": single, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
            "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
-    if steady is not None:
-        per_gpu_ms = steady["ms_per_step"]
-        steady["valu"] = {"unit": "field-mult/s", "achieved": fm_per_proof * 1e3 / per_gpu_ms, "peak": peak_fm,
-                          "frac": fm_per_proof * 1e3 / per_gpu_ms / peak_fm if peak_fm else None,
-                          "counted": "field multiplications of the bucket sweeps and the generator folds only (%.3g per proof)" % fm_per_proof}
-        steady["hbm"] = {"achieved": b_alg * 1e3 / per_gpu_ms / 1e9, "unit": "GB/s", "frac": b_alg * 1e3 / per_gpu_ms / 8e12}
-        out["steady_state"] = steady
+    if completions is not None:
+        out["completions"] = completions
     if gpu_ms_per_proof is not None:
         out["gpu_busy"] = {"kernel_ms_per_proof": gpu_ms_per_proof, "fraction_of_step": gpu_ms_per_proof / (t_step * 1e3),
                            "note": "sum of the HIP-event durations of every kernel of one (untimed) proof / ms_per_step"}

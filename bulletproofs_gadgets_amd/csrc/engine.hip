@@ -375,6 +375,7 @@ Engine::Engine(int device) : device_(device) {
     if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available: the bpg engine has no CPU path");
     if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
     HIPCHK(hipSetDevice(device));
+    if (const char *e = std::getenv("BPG_SYNC_BLOCKING")) { if (std::atoi(e) != 0) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
     impl_ = new Impl();
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;

@@ -3,7 +3,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02 calib stats pmc'      and      gpurun --timeout 900 -- 'bash tools/profile_round.sh r02 bench'
 # stages (any subset, in this order):
 #   calib  FETCH_SIZE calibration on a known byte count (tools/calib/gather_calib.hip)          -> gpurun_out/<tag>_fetch_calibration.json
-#   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only (as timed: two streams), of the same with one stream and
+#   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only (as timed: 14 proving streams), of the same with one stream and
 #          one chain thread (kernels alone on the GPU), and of --in-flight-only  -> gpurun_out/<tag>_stats/, <tag>_stats_single/, <tag>_stats_inflight/
 #   pmc    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only                -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/, <tag>_pmc_traffic.json
 #   bench  the default bench line exactly as the driver runs it (cpu_baseline, throughput, batch) -> gpurun_out/<tag>_bench_plain.json
