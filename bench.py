@@ -4,10 +4,11 @@
 One "step" = one Prover::prove (reference src/bin/prover.rs:93) of the reference's own 2^20 circuit - the full
 512-leaf MiMC Merkle tree of src/merkle_tree/merkle_tree_gadget.rs:473-545 (n = 993,384 multipliers padded to
 N = 2^20, q = 1,986,769 constraints, m = 512 commitments) - with the flattened instance and the generator tables
-already resident in HBM.  Steps are independent proofs (own seed) proved one after the other on one HIP stream; their serial
-TranscriptRng chains (0.3 s of host work each, upstream-exact) are drawn ahead by the rank's chain worker on --chain-workers host
-threads (default 10: the GPU sets the pace; 1 = one host thread, reported as `single_stream`); every chain of the K timed steps
-starts and ends inside the timed region.
+already resident in HBM.  Steps are independent proofs (own seed), dealt round-robin to --streams proving streams per GPU (engine
+contexts: own HIP stream and proving thread, generator tables shared); their serial TranscriptRng chains (0.3 s of host work each,
+upstream-exact) are drawn by --chain-workers host threads, shared out over the streams (defaults: 14 streams with one chain thread
+each; `--streams 1 --chain-workers 1` = one stream, one host thread, reported as `single_stream`); every chain of the K timed
+steps starts and ends inside the timed region.
 
 `--gpus N` (N > 1) without a torchrun environment: this process spawns N ranks itself (fresh child processes, before anything
 touches torch or the GPU) and relays rank 0's line.  Under torchrun it is one rank: one process per GPU, each rank proves its
