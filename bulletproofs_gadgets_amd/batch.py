@@ -9,9 +9,10 @@ def shard_indices(num_proofs: int, rank: int, world: int):
     return list(range(rank, num_proofs, world))
 
 
-def gather_proofs(local: dict, num_proofs: int, proof_len: int, dist=None, device="cpu"):
-    """local: {proof index: proof bytes} produced by this rank. Returns the full list (index order) on every rank."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def gather_proofs(local: dict, num_proofs: int, proof_len: int, dist=None, device="cpu", force_collective=False):
+    """local: {proof index: proof bytes} produced by this rank. Returns the full list (index order) on every rank.
+    force_collective: run the all_gather even in a world of one (the RCCL path on a one-GPU box, tests/test_batch_gpu.py)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return [local[i] for i in range(num_proofs)]
     world, rank = dist.get_world_size(), dist.get_rank()
     per_rank = (num_proofs + world - 1) // world

@@ -111,3 +111,58 @@ def test_bench_spawns_its_own_ranks():
     assert out["batch"]["proofs"] == 4 and out["batch"]["ranks"] == 2 and out["batch"]["proofs_per_rank"] == 2
     assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0
     assert out["throughput"]["ranks_failed"] == 0 and out["throughput"]["proofs_in_flight_per_gpu"] == 2 and out["throughput"]["value"] > 0
+
+
+RCCL_WORKER = textwrap.dedent('''
+    import os, sys, threading, traceback
+    def _report(t, v, tb):
+        sys.stdout.write("WORKER FAILED: " + "".join(traceback.format_exception(t, v, tb))); sys.stdout.flush()
+        os._exit(1)
+    sys.excepthook = _report
+    sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    import bulletproofs_gadgets_amd as bpg
+    from bulletproofs_gadgets_amd import workloads
+    from bulletproofs_gadgets_amd.batch import gather_proofs
+    import oracle_lib as O
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))          # "nccl" is RCCL on ROCm
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    ctx = bpg.Context(0)
+    a = workloads.mimc_preimage(ctx, nbytes=40, seed=2)
+    inst = a.prover.instance()
+    ctx.gens_ensure(a.gens_capacity)
+    res = ctx.upload(inst)
+    seed = lambda i: bytes([i + 1]) * 32
+    NUM = 4
+    local, gathered = {}, []
+    def prove_all():
+        for i in range(NUM):
+            local[i] = res.prove(a.transcript.state, inst.v_blinding, seed(i), 0)[0]
+    # the engine proves on its own HIP stream while RCCL collectives run on torch's: first side by side, then the real gather
+    th = threading.Thread(target=prove_all); th.start()
+    for _ in range(8):
+        gathered.append(gather_proofs({0: bytes(range(64))}, 1, 64, dist, device="cuda", force_collective=True))
+    th.join()
+    assert all(g == [bytes(range(64))] for g in gathered)
+    plen = len(local[0])
+    proofs = gather_proofs(local, NUM, plen, dist, device="cuda", force_collective=True)
+    oc = O.FlatCircuit(inst.n, inst.m, inst.aL, inst.aR, inst.aO, inst.row_ptr, inst.term_var, inst.term_coef, inst.coef)
+    for i in range(NUM):
+        rc, want, _ = O.prove(O.Gens(a.gens_capacity), a.transcript.state, oc, inst.v_blinding, seed(i), O.FLAG_FAST_MSM)
+        assert rc == 0 and proofs[i] == want, i
+    t = torch.ones(4, device="cuda"); dist.all_reduce(t); assert float(t.sum().item()) == 4.0
+    dist.barrier(); dist.destroy_process_group()
+    sys.stdout.write("rccl ok\\n"); sys.stdout.flush()
+''') % (str(ROOT), str(ROOT / "tests"), str(ROOT / "tests" / "golden"))
+
+
+def test_rccl_collectives_beside_engine_streams(tmp_path):
+    """The collective of the multi-GPU path as the 8-GPU runs issue it - backend "nccl" (RCCL), device tensors, torch's stream - in a world of
+    one on the one card of the box, while the engine proves on its own HIP stream; the gathered bytes are the oracle's."""
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(RCCL_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "rccl ok" in r.stdout
