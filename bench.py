@@ -450,6 +450,12 @@ def run_rank(args):
             acc = prof.setdefault(name, {k: 0 for k in v})
             for k in v:
                 acc[k] += v[k]
+    try:
+        free_b, total_b = torch.cuda.mem_get_info(device_index)
+        hbm_used = {"in_use_GB": (total_b - free_b) / 1e9, "total_GB": total_b / 1e9,
+                    "note": "device memory in use on this rank's GPU with all proving streams alive (generator tables and odd multiples once per device, workspaces per stream)"}
+    except Exception:       # noqa: BLE001
+        hbm_used = None
     del lanes[1:]                # the other legs use the first stream only
     for c2, r2 in extra_lanes:
         r2.free(); c2.close()
@@ -665,6 +671,8 @@ def run_rank(args):
            "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
     if completions is not None:
         out["completions"] = completions
+    if hbm_used is not None:
+        out["hbm_in_use"] = hbm_used
     if gpu_ms_per_proof is not None:
         out["gpu_busy"] = {"kernel_ms_per_proof": gpu_ms_per_proof, "fraction_of_step": gpu_ms_per_proof / (t_step * 1e3),
                            "note": "sum of the HIP-event durations of every kernel of one (untimed) proof / ms_per_step"}
