@@ -118,6 +118,16 @@ int32_t wnaf256(const Scalar &s, uint32_t w, int8_t d[256]) {
     return top;
 }
 
+// bits [from, from + count) of a canonical scalar as a scalar of its own (count <= 128)
+Scalar scalar_bits(const Scalar &s, uint32_t from, uint32_t count) {
+    Scalar r = Scalar::zero();
+    for (uint32_t k = 0; k < count && from + k < 256; k++) {
+        const uint32_t b = from + k;
+        if ((s.w[b >> 6] >> (b & 63)) & 1ull) r.w[k >> 6] |= 1ull << (k & 63);
+    }
+    return r;
+}
+
 uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; return l; }
 
 // On-disk cache of the generator tables (reference src/bin/prover.rs:92 re-derives them on every run).  Opt-in:
@@ -150,7 +160,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
@@ -218,25 +228,38 @@ struct Engine::Impl {
     PinBuf h_naf;
     // odd multiples 3P, 5P, .. (2^(w-1) - 1)P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf);
     // built on first use for the current generator tables, rebuilt when those are extended
-    DevBuf gens_odd;                 // view of shared->odd[fold_wnaf] (not owned)
+    DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
     uint32_t fold_wnaf = 8;
+    uint32_t fold_parts = 4;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2 or 4)
+    uint32_t fold_part_bits() const { return (254 + fold_parts - 1) / fold_parts; }
     void odd_ensure() {
         std::lock_guard<std::mutex> lk(shared->m);
-        auto it = shared->odd.find(fold_wnaf);
+        const uint32_t key = fold_wnaf | (fold_parts << 8);
+        auto it = shared->odd.find(key);
         if (it != shared->odd.end()) { gens_odd = it->second; return; }
-        const uint32_t nm = (1u << (fold_wnaf - 2)) - 1u, cnt = (uint32_t)(2 * gens_cap);
-        DevBuf odd; odd.ensure((size_t)nm * cnt * sizeof(ge_niels));
+        const uint32_t NM = 1u << (fold_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
+        DevBuf odd; odd.ensure(((size_t)fold_parts * NM - 1) * cnt * sizeof(ge_niels));
         scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
-        DevBuf dbl; dbl.ensure((size_t)cnt * sizeof(ge_ext));
-        BPG_LAUNCH((*this), k_odd_start, dim3(cdiv(cnt, 256)), dim3(256), gens.as<ge_niels>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
-        for (uint32_t m = 1; m <= nm; m++) {
-            if (m > 1) BPG_LAUNCH((*this), k_odd_step, dim3(cdiv(cnt, 256)), dim3(256), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
-            BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(cnt, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), odd.as<ge_niels>() + (size_t)(m - 1) * cnt, cnt);
+        DevBuf dbl, base; dbl.ensure((size_t)cnt * sizeof(ge_ext));
+        if (fold_parts > 1) base.ensure((size_t)cnt * sizeof(ge_ext));
+        const dim3 grid(cdiv(cnt, 256)), ngrid(cdiv(cdiv(cnt, NORM_K), 256));
+        for (uint32_t part = 0; part < fold_parts; part++) {
+            ge_niels *tab0 = odd.as<ge_niels>() + ((ptrdiff_t)part * NM - 1) * (ptrdiff_t)cnt;          // table (part, m) = tab0 + m * cnt; (0, 0) is the generator table
+            if (part == 0) BPG_LAUNCH((*this), k_odd_start, grid, dim3(256), gens.as<ge_niels>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
+            else {
+                BPG_LAUNCH((*this), k_dbl_times, grid, dim3(256), gens.as<ge_niels>(), base.as<ge_ext>(), cnt, L, part == 1 ? 1u : 0u);      // 2^(part*L) * P
+                BPG_LAUNCH((*this), k_normalize_niels, ngrid, dim3(256), base.as<ge_ext>(), tab0, cnt);
+                BPG_LAUNCH((*this), k_odd_start_ext, grid, dim3(256), base.as<ge_ext>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
+            }
+            for (uint32_t m = 1; m < NM; m++) {
+                if (m > 1) BPG_LAUNCH((*this), k_odd_step, grid, dim3(256), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
+                BPG_LAUNCH((*this), k_normalize_niels, ngrid, dim3(256), scratch_ext.as<ge_ext>(), tab0 + (size_t)m * cnt, cnt);
+            }
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
-        dbl.release();
-        shared->odd[fold_wnaf] = odd;
+        dbl.release(); base.release();
+        shared->odd[key] = odd;
         gens_odd = odd;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
@@ -389,6 +412,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_PARTS")) { int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) impl_->fold_parts = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
@@ -1013,7 +1037,8 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             if (use_wnaf) {
                 // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf)
                 I.odd_ensure();
-                const size_t dbytes = (size_t)4 * nterms * 256;
+                const uint32_t parts = I.fold_parts, L = I.fold_part_bits(), nq = nterms * parts;
+                const size_t dbytes = (size_t)4 * nq * 256;
                 I.h_naf.ensure(dbytes); I.naf.ensure(dbytes);
                 int8_t *hd = I.h_naf.as<int8_t>();
                 std::memset(hd, 0, dbytes);
@@ -1026,15 +1051,18 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                     const uint64_t lo = (uint64_t)t * Mr, nB = !g_first ? 0 : (lo >= n ? Mr : (lo + Mr > n ? lo + Mr - n : 0));
                     for (int cls = 0; cls < 4; cls++) {
                         if ((cls & 1) && !g_first) continue;
-                        int8_t *d = hd + ((size_t)cls * nterms + q) * 256;
-                        const int32_t tp = wnaf256(cls_s[cls], I.fold_wnaf, d);
-                        if (tp > top) top = tp;
-                        int adds = 0; for (int k = 0; k < 256; k++) adds += d[k] != 0;
-                        adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
+                        for (uint32_t part = 0; part < parts; part++) {
+                            int8_t *d = hd + ((size_t)cls * nq + (size_t)part * nterms + q) * 256;
+                            const int32_t tp = wnaf256(scalar_bits(cls_s[cls], part * L, L), I.fold_wnaf, d);
+                            if (tp > top) top = tp;
+                            int adds = 0; for (int k = 0; k < 256; k++) adds += d[k] != 0;
+                            adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
+                        }
                     }
                 }
                 HIPCHK(hipMemcpyAsync(I.naf.p, hd, dbytes, hipMemcpyHostToDevice, st));
                 FoldWnaf fw; fw.Mr = Mr; fw.nterms = nterms; fw.first_group = g_first; fw.n = (uint32_t)n; fw.cap = (uint32_t)gens_cap; fw.top = top;
+                fw.parts = parts; fw.NM = 1u << (I.fold_wnaf - 2);
                 BPG_LAUNCH(I, k_fold_points_wnaf, dim3(cdiv(2 * Mr, 256)), dim3(256), I.gens.as<ge_niels>(), I.gens_odd.as<ge_niels>(), I.scratch_ext.as<ge_ext>(),
                            I.naf.as<uint32_t>(), fw);
                 I.prof_note(KID_k_fold_points_wnaf, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * (2.0 * Mr + adds_fm / 7.0) + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);

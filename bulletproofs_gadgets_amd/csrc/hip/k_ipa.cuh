@@ -412,7 +412,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // affine Niels) and the shared scalars are recoded in width-w NAF: one addition per w+1 bits instead of one per 3 (36 instead of 84 per
 // term at w = 6), each addend read from memory when its digit comes up - lane i of a wave reads point i of the same table: coalesced, and
 // no addend lives in registers.  dig: [4 classes][nterms][256] signed odd digits (int8, 0 = none), class = 2*isH + isB as in k_fold_points.
-struct FoldWnaf { uint32_t Mr, nterms, first_group, n, cap; int32_t top; };
+// Split scalars (parts > 1): the generators never change, so the odd multiples of 2^(j*L) * P_p are tabulated as well (j < parts, L = ceil(254 / parts))
+// and a scalar s = sum_j s_j 2^(j*L) becomes `parts` short scalars on different tables: ONE chain of L doublings instead of 253 for the same
+// number of additions.  Table (part j, multiple 2m+1) sits at odd[(j * NM + m - 1) * tab] (NM = 2^(w-2); j = 0, m = 0 is the generator table itself).
+// dig: [4 classes][parts * nterms][256] with entry part * nterms + q holding the width-w NAF of part `part` of term q's scalar.
+struct FoldWnaf { uint32_t Mr, nterms, first_group, n, cap; int32_t top; uint32_t parts, NM; };
 __device__ __forceinline__ int32_t fold_wnaf_digit(const uint32_t *__restrict__ dig32, uint32_t cls, uint32_t nterms, uint32_t q, int k) {
     const uint32_t w = dig32[(cls * nterms + q) * 64u + ((uint32_t)k >> 2)];
     return (int32_t)(int8_t)(w >> (8u * ((uint32_t)k & 3u)));
@@ -432,28 +436,33 @@ __global__ void __launch_bounds__(256) k_fold_points_wnaf(const ge_niels *__rest
     const uint32_t key0 = __builtin_amdgcn_readfirstlane(key);
     const uint32_t hsel = isH ? 2u : 0u;
     ge_ext acc = ge_identity();
+    const uint32_t nq = fg.nterms * fg.parts;
     if (__ballot(key != key0) == 0ull) {                    // every lane agrees on the class of every term: scalar digit loads, scalar branches
         const uint32_t hs = (key0 >> 31) * 2u;
         for (int k = fg.top; k >= 0; k--) {
             acc = ge_dbl(acc);
-            for (uint32_t q = 0; q < fg.nterms; q++) {
-                const int32_t d = __builtin_amdgcn_readfirstlane(fold_wnaf_digit(dig32, hs + ((key0 >> q) & 1u), fg.nterms, q, k));
-                if (d != 0) {
-                    const uint32_t mag = (uint32_t)(d < 0 ? -d : d), m = mag >> 1;
-                    const ge_niels *T = m ? odd + (size_t)(m - 1) * tab : gens;
-                    acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+            for (uint32_t part = 0, e = 0; part < fg.parts; part++) {
+                for (uint32_t q = 0; q < fg.nterms; q++, e++) {
+                    const int32_t d = __builtin_amdgcn_readfirstlane(fold_wnaf_digit(dig32, hs + ((key0 >> q) & 1u), nq, e, k));
+                    if (d != 0) {
+                        const uint32_t mag = (uint32_t)(d < 0 ? -d : d), idx = part * fg.NM + (mag >> 1);
+                        const ge_niels *T = idx ? odd + (size_t)(idx - 1) * tab : gens;
+                        acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+                    }
                 }
             }
         }
     } else {
         for (int k = fg.top; k >= 0; k--) {
             acc = ge_dbl(acc);
-            for (uint32_t q = 0; q < fg.nterms; q++) {
-                const int32_t d = fold_wnaf_digit(dig32, hsel + ((bmask >> q) & 1u), fg.nterms, q, k);
-                if (d != 0) {
-                    const uint32_t mag = (uint32_t)(d < 0 ? -d : d), m = mag >> 1;
-                    const ge_niels *T = m ? odd + (size_t)(m - 1) * tab : gens;
-                    acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+            for (uint32_t part = 0, e = 0; part < fg.parts; part++) {
+                for (uint32_t q = 0; q < fg.nterms; q++, e++) {
+                    const int32_t d = fold_wnaf_digit(dig32, hsel + ((bmask >> q) & 1u), nq, e, k);
+                    if (d != 0) {
+                        const uint32_t mag = (uint32_t)(d < 0 ? -d : d), idx = part * fg.NM + (mag >> 1);
+                        const ge_niels *T = idx ? odd + (size_t)(idx - 1) * tab : gens;
+                        acc = ge_madd_signed(acc, T[base + (q + 1) * fg.Mr], d < 0);
+                    }
                 }
             }
         }
@@ -467,6 +476,22 @@ __global__ void __launch_bounds__(256) k_odd_start(const ge_niels *__restrict__ 
     const ge_ext e = ge_madd(ge_identity(), gens[p]);
     const ge_ext d = ge_dbl(e);
     cur[p] = ge_add(e, d); dbl[p] = d;                       // 3P
+}
+// the same from extended points (the 2^(j*L) multiples of the generators): cur = 3Q, dbl = 2Q
+__global__ void __launch_bounds__(256) k_odd_start_ext(const ge_ext *__restrict__ base, ge_ext *__restrict__ cur, ge_ext *__restrict__ dbl, uint32_t count) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    const ge_ext e = base[p];
+    const ge_ext d = ge_dbl(e);
+    cur[p] = ge_add(e, d); dbl[p] = d;
+}
+// pts[p] = 2^times * src[p]   (src = Niels generators when from_niels, else pts itself)
+__global__ void __launch_bounds__(256) k_dbl_times(const ge_niels *__restrict__ gens, ge_ext *__restrict__ pts, uint32_t count, uint32_t times, uint32_t from_niels) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    ge_ext e = from_niels ? ge_madd(ge_identity(), gens[p]) : pts[p];
+    for (uint32_t k = 0; k < times; k++) e = ge_dbl(e);
+    pts[p] = e;
 }
 __global__ void __launch_bounds__(256) k_odd_step(ge_ext *__restrict__ cur, const ge_ext *__restrict__ dbl, uint32_t count) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;

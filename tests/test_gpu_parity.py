@@ -703,6 +703,31 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     res.free()
 
 
+@pytest.mark.parametrize("parts,wnaf,group", [(1, 8, 3), (2, 8, 3), (4, 8, 3), (2, 5, 2), (4, 6, 1), (4, 3, 5), (1, 6, 4)])
+def test_split_scalar_fold_gives_identical_proofs(parts, wnaf, group, monkeypatch):
+    """The first generator fold cuts its shared scalars into `parts` pieces on tables of 2^(j*L) * P (one chain of L = ceil(254/parts) doublings
+    instead of 253): same bytes as the oracle for every split, NAF width and group size, with padding generators in the first group."""
+    monkeypatch.setenv("BPG_TT_LG", "0")
+    monkeypatch.setenv("BPG_FOLD_SPLIT", "0")            # the width-w NAF fold at this small size
+    monkeypatch.setenv("BPG_FOLD_GROUP", str(group))
+    monkeypatch.setenv("BPG_FOLD_WNAF", str(wnaf))
+    monkeypatch.setenv("BPG_FOLD_PARTS", str(parts))
+    monkeypatch.setenv("BPG_GENS_SHARE", "0")
+    c = bpg.Context(0)
+    try:
+        for nbytes, seed in ((20, 3), (50, 5)):            # n = 972 (N = 1024: 52 padding generators) and n = 1944 (N = 2048)
+            a = workloads.mimc_preimage(c, nbytes=nbytes, seed=seed, label=b"MiMCHash")
+            inst = a.prover.instance()
+            c.gens_ensure(a.gens_capacity)
+            res = c.upload(inst)
+            proof, st_after = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)
+            rc, want, st_want = O.prove(O.Gens(a.gens_capacity), a.transcript.state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
+            assert rc == 0 and proof == want and st_after == st_want
+            res.free()
+    finally:
+        c.close()
+
+
 def test_contexts_of_one_device_share_generator_tables(monkeypatch):
     """Contexts of one device share their generator tables and the odd multiples of the width-w NAF fold (engine.hip SharedTables): two contexts prove
     side by side on their own streams from the same tables, the tables outlive the context that derived them, and a context that asks for a
