@@ -62,7 +62,7 @@ struct SharedTables {
     int device = 0; uint64_t cap = 0;
     DevBuf gens;
     std::mutex m;                                   // guards odd (construction on first use)
-    std::map<uint32_t, DevBuf> odd;                 // w -> [(2^(w-2) - 1)][2*cap] Niels points
+    std::map<uint32_t, DevBuf> odd;                 // (w | parts << 8) -> [parts * 2^(w-2) - 1][2*cap] Niels points: (2m+1) * 2^(j*L) * P, see FoldWnaf
     ~SharedTables() { (void)hipSetDevice(device); gens.release(); for (auto &kv : odd) kv.second.release(); }
 };
 static std::mutex g_tables_mutex;                   // held across a derivation: contexts created side by side derive once
@@ -226,14 +226,20 @@ struct Engine::Impl {
         if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
     }
     PinBuf h_naf;
-    // odd multiples 3P, 5P, .. (2^(w-1) - 1)P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf);
-    // built on first use for the current generator tables, rebuilt when those are extended
+    // odd multiples (2m+1) * 2^(j*L) * P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf, scalars
+    // cut into `fold_parts` pieces of L bits); built on first use for the device's generator tables and shared with them
     DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
     uint32_t fold_wnaf = 8;
     uint32_t fold_parts = 4;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2 or 4)
-    uint32_t fold_part_bits() const { return (254 + fold_parts - 1) / fold_parts; }
+    uint64_t fold_table_budget = 64ull << 30;       // bytes of HBM the fold tables of one device may take (BPG_FOLD_TABLE_GB): larger capacities get fewer parts, then narrower windows
+    uint32_t eff_wnaf = 0, eff_parts = 0;            // what odd_ensure settled on for the current capacity
+    uint32_t fold_part_bits() const { return (254 + eff_parts - 1) / eff_parts; }
     void odd_ensure() {
+        eff_wnaf = fold_wnaf; eff_parts = fold_parts;
+        auto table_bytes = [&](uint32_t w, uint32_t parts) { return ((uint64_t)parts * (1u << (w - 2)) - 1) * 2 * gens_cap * sizeof(ge_niels); };
+        while (table_bytes(eff_wnaf, eff_parts) > fold_table_budget && (eff_parts > 1 || eff_wnaf > 3)) { if (eff_parts > 1) eff_parts /= 2; else eff_wnaf--; }
         std::lock_guard<std::mutex> lk(shared->m);
+        const uint32_t fold_wnaf = eff_wnaf, fold_parts = eff_parts;       // (shadow the requested values below)
         const uint32_t key = fold_wnaf | (fold_parts << 8);
         auto it = shared->odd.find(key);
         if (it != shared->odd.end()) { gens_odd = it->second; return; }
@@ -412,6 +418,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_FOLD_TABLE_GB")) { double v = std::atof(e); if (v > 0 && v <= 4096) impl_->fold_table_budget = (uint64_t)(v * (double)(1ull << 30)); }
     if (const char *e = std::getenv("BPG_FOLD_PARTS")) { int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) impl_->fold_parts = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
@@ -1037,7 +1044,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             if (use_wnaf) {
                 // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf)
                 I.odd_ensure();
-                const uint32_t parts = I.fold_parts, L = I.fold_part_bits(), nq = nterms * parts;
+                const uint32_t parts = I.eff_parts, L = I.fold_part_bits(), nq = nterms * parts;
                 const size_t dbytes = (size_t)4 * nq * 256;
                 I.h_naf.ensure(dbytes); I.naf.ensure(dbytes);
                 int8_t *hd = I.h_naf.as<int8_t>();
@@ -1053,7 +1060,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                         if ((cls & 1) && !g_first) continue;
                         for (uint32_t part = 0; part < parts; part++) {
                             int8_t *d = hd + ((size_t)cls * nq + (size_t)part * nterms + q) * 256;
-                            const int32_t tp = wnaf256(scalar_bits(cls_s[cls], part * L, L), I.fold_wnaf, d);
+                            const int32_t tp = wnaf256(scalar_bits(cls_s[cls], part * L, L), I.eff_wnaf, d);
                             if (tp > top) top = tp;
                             int adds = 0; for (int k = 0; k < 256; k++) adds += d[k] != 0;
                             adds_fm += 7.0 * adds * ((cls & 1) ? (double)nB : (double)(Mr - nB));
@@ -1062,7 +1069,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 }
                 HIPCHK(hipMemcpyAsync(I.naf.p, hd, dbytes, hipMemcpyHostToDevice, st));
                 FoldWnaf fw; fw.Mr = Mr; fw.nterms = nterms; fw.first_group = g_first; fw.n = (uint32_t)n; fw.cap = (uint32_t)gens_cap; fw.top = top;
-                fw.parts = parts; fw.NM = 1u << (I.fold_wnaf - 2);
+                fw.parts = parts; fw.NM = 1u << (I.eff_wnaf - 2);
                 BPG_LAUNCH(I, k_fold_points_wnaf, dim3(cdiv(2 * Mr, 256)), dim3(256), I.gens.as<ge_niels>(), I.gens_odd.as<ge_niels>(), I.scratch_ext.as<ge_ext>(),
                            I.naf.as<uint32_t>(), fw);
                 I.prof_note(KID_k_fold_points_wnaf, 32.0 * (2.0 * g_M + 2.0 * Mr), 96.0 * (2.0 * Mr + adds_fm / 7.0) + 128.0 * 2 * Mr, 2.0 * Mr * (8.0 * (top + 1) + 7.0) + adds_fm);

@@ -703,10 +703,14 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     res.free()
 
 
-@pytest.mark.parametrize("parts,wnaf,group", [(1, 8, 3), (2, 8, 3), (4, 8, 3), (2, 5, 2), (4, 6, 1), (4, 3, 5), (1, 6, 4)])
-def test_split_scalar_fold_gives_identical_proofs(parts, wnaf, group, monkeypatch):
+@pytest.mark.parametrize("parts,wnaf,group,budget_gb", [(1, 8, 3, None), (2, 8, 3, None), (4, 8, 3, None), (2, 5, 2, None), (4, 6, 1, None), (4, 3, 5, None), (1, 6, 4, None),
+                                                         (4, 8, 3, "0.01"), (4, 8, 2, "0.03"), (2, 7, 3, "0.0001")])
+def test_split_scalar_fold_gives_identical_proofs(parts, wnaf, group, budget_gb, monkeypatch):
     """The first generator fold cuts its shared scalars into `parts` pieces on tables of 2^(j*L) * P (one chain of L = ceil(254/parts) doublings
-    instead of 253): same bytes as the oracle for every split, NAF width and group size, with padding generators in the first group."""
+    instead of 253): same bytes as the oracle for every split, NAF width and group size, with padding generators in the first group; a table
+    budget (BPG_FOLD_TABLE_GB) below what the requested profile needs makes the engine fall back to fewer parts, then narrower windows."""
+    if budget_gb is not None:
+        monkeypatch.setenv("BPG_FOLD_TABLE_GB", budget_gb)
     monkeypatch.setenv("BPG_TT_LG", "0")
     monkeypatch.setenv("BPG_FOLD_SPLIT", "0")            # the width-w NAF fold at this small size
     monkeypatch.setenv("BPG_FOLD_GROUP", str(group))

@@ -15,7 +15,7 @@ for mode in ("two_pass", "single_pass"):
     out["n"] = workloads.merkle_tree_files(str(d / "tree"), leaves=leaves)
     env = dict(os.environ, BPG_CLI_SEED="e2e", BPG_CLI_RNG_SEED="22" * 32, BPG_CLI_TIMING="1", BPG_CLI_TWO_PASS="1" if mode == "two_pass" else "0")
     best = None
-    for rep in range(2):
+    for rep in range(4):
         t0 = time.perf_counter()
         r = subprocess.run([str(prover_bin), "tree"], cwd=d, env=env, capture_output=True, text=True, timeout=600)
         dt = time.perf_counter() - t0
