@@ -239,17 +239,16 @@ struct Engine::Impl {
         auto table_bytes = [&](uint32_t w, uint32_t parts) { return ((uint64_t)parts * (1u << (w - 2)) - 1) * 2 * gens_cap * sizeof(ge_niels); };
         while (table_bytes(eff_wnaf, eff_parts) > fold_table_budget && (eff_parts > 1 || eff_wnaf > 3)) { if (eff_parts > 1) eff_parts /= 2; else eff_wnaf--; }
         std::lock_guard<std::mutex> lk(shared->m);
-        const uint32_t fold_wnaf = eff_wnaf, fold_parts = eff_parts;       // (shadow the requested values below)
-        const uint32_t key = fold_wnaf | (fold_parts << 8);
+        const uint32_t key = eff_wnaf | (eff_parts << 8);
         auto it = shared->odd.find(key);
         if (it != shared->odd.end()) { gens_odd = it->second; return; }
-        const uint32_t NM = 1u << (fold_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
-        DevBuf odd; odd.ensure(((size_t)fold_parts * NM - 1) * cnt * sizeof(ge_niels));
+        const uint32_t NM = 1u << (eff_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
+        DevBuf odd; odd.ensure(((size_t)eff_parts * NM - 1) * cnt * sizeof(ge_niels));
         scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
         DevBuf dbl, base; dbl.ensure((size_t)cnt * sizeof(ge_ext));
-        if (fold_parts > 1) base.ensure((size_t)cnt * sizeof(ge_ext));
+        if (eff_parts > 1) base.ensure((size_t)cnt * sizeof(ge_ext));
         const dim3 grid(cdiv(cnt, 256)), ngrid(cdiv(cdiv(cnt, NORM_K), 256));
-        for (uint32_t part = 0; part < fold_parts; part++) {
+        for (uint32_t part = 0; part < eff_parts; part++) {
             ge_niels *tab0 = odd.as<ge_niels>() + ((ptrdiff_t)part * NM - 1) * (ptrdiff_t)cnt;          // table (part, m) = tab0 + m * cnt; (0, 0) is the generator table
             if (part == 0) BPG_LAUNCH((*this), k_odd_start, grid, dim3(256), gens.as<ge_niels>(), scratch_ext.as<ge_ext>(), dbl.as<ge_ext>(), cnt);
             else {

@@ -2,13 +2,15 @@
 // no MFMA - this is 255-bit modular arithmetic, not a dense contraction.  Hot-path rows of SURVEY.md section 8(a):
 //   a7  BulletproofGens::new            k_gens_derive + k_normalize_niels
 //   a1-a3,a6  Pedersen commits          k_pedersen (window tables of B and B_blinding: k_tt_bases, k_tt_multiples)
-//   a9  A_I, A_O, S multiscalar muls    k_msm_plain, k_msm_tile<0/1>, k_msm_tile_prefix, k_scan_*, k_bucket_chunks, k_bucket_combine(_heavy),
-//                                       k_bucket_reduce, k_window_sums, k_msm_horner (bucket method: LDS tile histograms -> scan -> scatter ->
-//                                       balanced bucket sweep -> reductions)
+//   a9  A_I, A_O, S multiscalar muls    k_msm_digits, k_msm_count1, k_scan_*, k_msm_scatter1, k_msm_sort2 (two-level sort; k_msm_plain / k_msm_tile<0/1> /
+//                                       k_msm_tile_prefix = the one-level sort), k_bucket_chunks, k_bucket_combine(_heavy), k_bucket_reduce, k_window_sums
+//                                       (bucket method: digits -> coarse partition in LDS -> fine counting sort -> balanced bucket sweep -> reductions;
+//                                       the 17 window sums are recombined and encoded on the host, host/fe51.hpp)
 //   a10 vector-polynomial phase         k_exp_table, k_flatten, k_poly_t, k_poly_eval, k_reduce_partials
-//   a11 inner-product argument          above 2^14 generators: k_ipa_prep, the MSM kernels, k_tt_advance, k_fold_points / k_fold_points_reg<NT> /
-//                                       k_fold_points_split once per group of rounds; below: k_tt_bases, k_tt_multiples, k_tt_factors, then
-//                                       k_tt_advance, k_tt_round, k_tt_finish per round
+//   a11 inner-product argument          above 2^14 generators: k_ipa_prep, the MSM kernels, k_tt_advance, one generator fold per group of rounds -
+//                                       k_fold_points_wnaf on the original generators (tables of (2m+1) * 2^(64j) * P: k_odd_start(_ext), k_odd_step,
+//                                       k_dbl_times), k_fold_points_quad / _split / _reg<NT> / k_fold_points on folded ones; below: k_tt_bases,
+//                                       k_tt_multiples, k_tt_factors, then k_tt_advance, k_tt_round, k_tt_finish per round
 //   f1  Verifier::verify                k_decompress, k_flatten_const, k_ipa_s, k_verify_scalars + one MSM
 // The kernels live in k_points.cuh, k_scalars.cuh, k_ipa.cuh, k_verify.cuh and k_msm.cuh, included at the end of this file in that order.
 // Data layout in HBM: scalars = 8 x u32 Montgomery form, 32 B each, AoS (lane i <-> element i: 2 x 16 B coalesced
