@@ -110,6 +110,10 @@ def test_bench_spawns_its_own_ranks():
     assert sorted(x["rank"] for x in out["ranks_seen"]) == [0, 1]
     assert out["batch"]["proofs"] == 4 and out["batch"]["ranks"] == 2 and out["batch"]["proofs_per_rank"] == 2
     assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):       # the roofline object of the driver contract
+        assert key in out["roofline"], key
+    assert out["unit"] == "constraints/s" and out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "u32"
+    assert "workload" in out["config"] and out["completions"]["last_ms"] > 0 and "cpu_baseline" not in out
     assert out["throughput"]["ranks_failed"] == 0 and out["throughput"]["proofs_in_flight_per_gpu"] == 2 and out["throughput"]["value"] > 0
 
 
