@@ -62,8 +62,9 @@ struct SharedTables {
     int device = 0; uint64_t cap = 0;
     DevBuf gens;
     std::mutex m;                                   // guards odd (construction on first use)
+    std::map<uint32_t, DevBuf> wide;                // M0 -> 8-bit window tables of G[0..M0), H[0..M0) for a tail that starts on the original generators (k_tt_round8)
     std::map<uint32_t, DevBuf> odd;                 // (w | parts << 8) -> [parts * 2^(w-2) - 1][2*cap] Niels points: (2m+1) * 2^(j*L) * P, see FoldWnaf
-    ~SharedTables() { (void)hipSetDevice(device); gens.release(); for (auto &kv : odd) kv.second.release(); }
+    ~SharedTables() { (void)hipSetDevice(device); gens.release(); for (auto &kv : odd) kv.second.release(); for (auto &kv : wide) kv.second.release(); }
 };
 static std::mutex g_tables_mutex;                   // held across a derivation: contexts created side by side derive once
 static std::map<std::pair<int, uint64_t>, std::weak_ptr<SharedTables>> g_tables;
@@ -162,7 +163,7 @@ struct DeviceCircuit {
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -224,6 +225,24 @@ struct Engine::Impl {
         BPG_LAUNCH((*this), k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), G, H, B, tt_bases.as<ge_ext>(), M0);
         BPG_LAUNCH((*this), k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), tt_bases.as<ge_ext>(), tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
         if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
+    }
+    // 8-bit window tables of the original generators (kernels.cuh k_tt_round8): shared per device like the fold tables, built on first use
+    uint64_t tt_wide_budget = 24ull << 30;      // BPG_TT_WIDE_GB; 0 = never (17.2 GB at M0 = 2^14)
+    const ge_pniels *wide_ensure(uint32_t M0) {
+        const uint64_t bytes = (uint64_t)2 * M0 * TT8_WINDOWS * TT8_MULTS * sizeof(ge_pniels);
+        if (M0 < 64 || bytes > tt_wide_budget) return nullptr;
+        std::lock_guard<std::mutex> lk(shared->m);
+        auto it = shared->wide.find(M0);
+        if (it != shared->wide.end()) return it->second.as<ge_pniels>();
+        DevBuf table, bases8;
+        table.ensure(bytes); bases8.ensure((size_t)2 * M0 * TT8_WINDOWS * sizeof(ge_ext));
+        BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
+        BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(st));
+        bases8.release();
+        shared->wide[M0] = table;
+        return table.as<ge_pniels>();
     }
     PinBuf h_naf;
     // odd multiples (2m+1) * 2^(j*L) * P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf, scalars
@@ -417,6 +436,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TT_WIDE_GB")) { double v = std::atof(e); if (v >= 0 && v <= 4096) impl_->tt_wide_budget = (uint64_t)(v * (double)(1ull << 30)); }
     if (const char *e = std::getenv("BPG_FOLD_TABLE_GB")) { double v = std::atof(e); if (v > 0 && v <= 4096) impl_->fold_table_budget = (uint64_t)(v * (double)(1ull << 30)); }
     if (const char *e = std::getenv("BPG_FOLD_PARTS")) { int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) impl_->fold_parts = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
@@ -934,7 +954,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
     const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
     uint64_t mcur = N;
     // table-driven tail state (kernels.cuh "table-driven IPA tail")
-    bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv;
+    bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv; const ge_pniels *tt_wide = nullptr;
     // grouped-fold state
     const uint32_t GRP_STRIDE = 64;
     uint32_t g_j = 0, g_r = 1, g_cur = 0, g_index = 0; uint64_t g_M = N; bool g_first = true; std::vector<Scalar> g_us;
@@ -947,6 +967,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             const uint32_t M0 = (uint32_t)mcur;
             I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
             I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_lg)
+            tt_wide = (Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>()) ? I.wide_ensure(M0) : nullptr;       // original generators: 8-bit windows, built once per device
             BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
                        I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
         }
@@ -959,7 +980,8 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 tt_cur ^= 1u; std::swap(c0, c1);
             }
             const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
-            BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
+            if (tt_wide) BPG_LAUNCH(I, k_tt_round8, dim3(nblk, 2), dim3(256), tt_wide, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j, I.tt_partial.as<ge_ext>());
+            else BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
                        I.tt_partial.as<ge_ext>());
             BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
                        I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());

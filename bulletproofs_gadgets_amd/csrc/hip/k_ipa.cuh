@@ -203,6 +203,84 @@ __global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ 
     }
     if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
 }
+// Wide tables for a tail that starts on the ORIGINAL generators (circuits up to 2^14 multipliers freeze at round 0): those never change, so a
+// table of k * 2^(8w) * P (w < 32 windows of 8 bits, k = 1..128, 512 KB per point, built once per device) halves the additions of every round:
+// 32 per base point instead of 64, 4 per thread instead of 8.  Same layout of threads and partials as k_tt_round.
+#define TT8_WINDOWS 32
+#define TT8_MULTS 128
+__global__ void __launch_bounds__(256) k_tt_bases8(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, ge_ext *__restrict__ bases, uint32_t M0) {
+    __shared__ CoopLds L;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t count = 2 * M0;
+    const uint32_t p = blockIdx.x * 64 + lane;
+    const bool live = p < count;
+    const uint32_t q_idx = live ? p : count - 1;
+    if (wv == 0) {
+        const ge_niels q = q_idx < M0 ? G[q_idx] : H[q_idx - M0];
+        const ge_ext e = ge_madd(ge_identity(), q);
+        coop_st(L.c[0], lane, e.X); coop_st(L.c[1], lane, e.Y); coop_st(L.c[2], lane, e.Z); coop_st(L.c[3], lane, e.T);
+    }
+    __syncthreads();
+    fe *dst = reinterpret_cast<fe *>(bases + (size_t)q_idx * TT8_WINDOWS) + wv;
+    for (uint32_t w = 0; w < TT8_WINDOWS; w++) {
+        if (live) dst[4 * w] = coop_ld(L.c[wv], lane);
+        if (w + 1 < TT8_WINDOWS) for (int k = 0; k < 8; k++) coop_dbl(L, wv, lane);
+    }
+}
+// table[i * 128 + k] = (k + 1) * bases[i], i = p * 32 + w
+__global__ void __launch_bounds__(256) k_tt_multiples8(const ge_ext *__restrict__ bases, ge_pniels *__restrict__ table, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ge_pniels *dst = table + (size_t)i * TT8_MULTS;
+    ge_ext cur = bases[i];
+    const ge_pniels n1 = ge_to_pniels(cur);
+    dst[0] = n1;
+#pragma unroll 1
+    for (uint32_t k = 1; k < TT8_MULTS; k++) { cur = ge_add_pniels_signed(cur, n1, 0); dst[k] = ge_to_pniels(cur); }
+}
+// signed 8-bit digits without a carry chain: byte w of (s + 0x80..80) minus 128 lies in [-128, 127]
+__device__ __forceinline__ void tt8_biased_words(uint32_t w[8], const scm &s) {
+    sc_to_words(w, s);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + 0x80808080ull + carry; w[k] = (uint32_t)t; carry = t >> 32; }
+}
+__global__ void __launch_bounds__(256) k_tt_round8(const ge_pniels *__restrict__ table, const scm *__restrict__ a, const scm *__restrict__ b,
+                                                   const scm *__restrict__ fG, const scm *__restrict__ fH, const scm *__restrict__ c,
+                                                   uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */) {
+    __shared__ ge_ext lds[256];
+    const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M0 = 1u << lgM0, e = tid >> 3, g = tid & 7u;
+    ge_ext acc = ge_identity();
+    if (e < M0) {
+        const bool isH = e >= (M0 >> 1);
+        const uint32_t e2 = isH ? e - (M0 >> 1) : e;
+        const uint32_t lgh = lgM0 - j - 1, h = 1u << lgh;
+        const uint32_t t = e2 >> lgh, i = e2 & (h - 1);
+        const bool hi = (cls == 0) != isH;                         // L: G_hi and H_lo;  R: G_lo and H_hi
+        const uint32_t p = (t << (lgh + 1)) | (hi ? h : 0u) | i;
+        const uint32_t sidx = hi ? i : (h | i);
+        scm s = isH ? b[sidx] : a[sidx];
+        s = sc_mont_mul(s, isH ? fH[p] : fG[p]);
+        s = sc_mont_mul(s, c[(isH ? M0 : 0u) + t]);
+        uint32_t w[8]; tt8_biased_words(w, s);
+        const ge_pniels *tbl = table + ((size_t)(isH ? M0 : 0u) + p) * (TT8_WINDOWS * TT8_MULTS) + (size_t)g * 4 * TT8_MULTS;
+        const uint32_t word = w[g];
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; k++) {
+            const int32_t d = (int32_t)((word >> (8 * k)) & 255u) - 128;
+            if (d == 0) continue;
+            const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
+            acc = ge_add_pniels_signed(acc, tbl[k * TT8_MULTS + mag - 1], neg);
+        }
+    }
+    lds[threadIdx.x] = acc; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+}
 // A_I, A_O, S of a circuit whose generators already have window tables (N <= 2^14: the tables of the frozen IPA tail are those of
 // the original generators and live with the context): blockIdx.y = 0: <a_L,G> + <a_R,H>, 1: <a_O,G>, 2: <s_L,G> + <s_R,H>; same thread
 // layout as k_tt_round (8 threads per base point, 8 windows each), block partials to partial[3][gridDim.x].

@@ -732,6 +732,32 @@ def test_split_scalar_fold_gives_identical_proofs(parts, wnaf, group, budget_gb,
         c.close()
 
 
+@pytest.mark.parametrize("wide_gb", ["0", "24"])
+def test_tail_on_original_generators_with_and_without_wide_tables(wide_gb, monkeypatch):
+    """Circuits up to 2^14 multipliers freeze their generators at round 0; the tail then reads 8-bit window tables of the original generators
+    (k_tt_round8, built once per device) unless BPG_TT_WIDE_GB forbids them: same bytes as the oracle either way, padding generators included,
+    also for the second proof on the same context (cached tables) and for a circuit of another size on the same context."""
+    monkeypatch.setenv("BPG_TT_WIDE_GB", wide_gb)
+    monkeypatch.setenv("BPG_GENS_SHARE", "0")
+    c = bpg.Context(0)
+    try:
+        cases = [workloads.mimc_preimage(c, nbytes=20, seed=3, label=b"MiMCHash"),      # n = 972, N = 1024
+                 workloads.bounds_check_64(c, seed=1),                                  # n = N = 128
+                 workloads.mimc_preimage(c, nbytes=100, seed=4)]                        # N = 4096
+        for a in cases:
+            inst = a.prover.instance()
+            c.gens_ensure(a.gens_capacity)
+            res = c.upload(inst)
+            og = O.Gens(a.gens_capacity)
+            for k in range(2):
+                proof, st_after = res.prove(a.transcript.state, inst.v_blinding, bytes([k + 7]) * 32, 0)
+                rc, want, st_want = O.prove(og, a.transcript.state, to_oracle(inst), inst.v_blinding, bytes([k + 7]) * 32, O.FLAG_FAST_MSM)
+                assert rc == 0 and proof == want and st_after == st_want
+            res.free()
+    finally:
+        c.close()
+
+
 def test_contexts_of_one_device_share_generator_tables(monkeypatch):
     """Contexts of one device share their generator tables and the odd multiples of the width-w NAF fold (engine.hip SharedTables): two contexts prove
     side by side on their own streams from the same tables, the tables outlive the context that derived them, and a context that asks for a
