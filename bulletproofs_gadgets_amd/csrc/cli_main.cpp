@@ -539,6 +539,7 @@ int main(int argc, char **argv) {
     // a one-shot run makes ONE proof: the small fold tables (15 odd multiples, 7 ms to build at 2^20) instead of the serving profile
     // (4 x 64 tables, 0.12 s to build, 1.7 ms less per proof); an explicit setting in the environment wins
     setenv("BPG_FOLD_WNAF", "6", 0); setenv("BPG_FOLD_PARTS", "1", 0);
+    setenv("BPG_TT_WIDE_GB", "0", 0);          // likewise no 8-bit tail tables (17 GB at 2^14 for 0.6 ms per proof)
     try {
         if (mode == "prover") { ProverRun r; r.name = name; return r.run(); }
         VerifierRun r; r.name = name; return r.run();
