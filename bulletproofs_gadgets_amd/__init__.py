@@ -277,6 +277,10 @@ class Context:
             raise ValueError("v_blinding must be a multiple of 32 bytes")
         _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, _seed32(rng_seed), C.c_uint64(max_multipliers)))
 
+    def set_chain_lanes(self, lanes: int):
+        """bpg_ctx_set_chain_lanes: queued blinding streams each chain thread draws in lockstep (1..8; workers * lanes + 1 streams may be alive)."""
+        _chk(lib().bpg_ctx_set_chain_lanes(self._h, C.c_uint32(lanes)))
+
     def set_chain_workers(self, workers: int):
         """bpg_ctx_set_chain_workers: threads that draw queued blinding streams side by side (workers + 1 streams may be alive)."""
         _chk(lib().bpg_ctx_set_chain_workers(self._h, C.c_uint32(workers)))

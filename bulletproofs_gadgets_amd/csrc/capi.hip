@@ -388,6 +388,7 @@ bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[203],
 }
 
 bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers) { return guard([&] { REQUIRE(ctx); ctx->engine->set_chain_workers(workers); }); }
+bpg_status bpg_ctx_set_chain_lanes(bpg_ctx *ctx, uint32_t lanes) { return guard([&] { REQUIRE(ctx); ctx->engine->set_chain_lanes(lanes); }); }
 int32_t bpg_chain_cpu(bpg_ctx *ctx) { return ctx ? ctx->engine->chain_cpu() : -1; }
 
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t seed[32], uint32_t flags, uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings) {
@@ -561,6 +562,28 @@ bpg_status bpg_rng_draws(const uint8_t transcript_state[203], uint64_t m, const 
         for (uint64_t i = 0; i < skip; i++) rng.fill_bytes(tmp, 64);
         if (bulk) rng.fill_draws64(out, count);
         else for (uint64_t i = 0; i < count; i++) rng.fill_bytes(out + 64 * i, 64);
+    });
+}
+bpg_status bpg_rng_draws_multi(const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, uint32_t lanes, const uint8_t *rng_seeds,
+                               const uint64_t *skip, uint64_t count, uint8_t *out) {
+    return guard([&] {
+        REQUIRE(transcript_state && rng_seeds && skip && out && lanes >= 1 && lanes <= 8 && (m == 0 || v_blinding));
+        Transcript t = Transcript::from_state(transcript_state);
+        std::vector<Scalar> vb(m);
+        for (uint64_t i = 0; i < m; i++) std::memcpy(vb[i].w, v_blinding + 32 * i, 32);
+        std::vector<TranscriptRng> rngs;
+        for (uint32_t v = 0; v < lanes; v++) {
+            rngs.push_back(t.build_rng(vb, rng_seeds + 32 * v));
+            uint8_t tmp[64];
+            for (uint64_t i = 0; i < skip[v]; i++) rngs.back().fill_bytes(tmp, 64);
+        }
+        TranscriptRng *r[8]; uint8_t *dst[8];
+        for (uint32_t v = 0; v < lanes; v++) { r[v] = &rngs[v]; dst[v] = out + (size_t)v * 64 * count; }
+        // in two calls, so that the second starts from the state the first left behind
+        const uint64_t first = count / 3;
+        TranscriptRng::fill_draws64_multi(r, dst, lanes, first);
+        for (uint32_t v = 0; v < lanes; v++) dst[v] += 64 * first;
+        TranscriptRng::fill_draws64_multi(r, dst, lanes, count - first);
     });
 }
 bpg_status bpg_keccak_selftest(uint64_t seed, uint32_t rounds, int32_t *impl_out, double *ns_out) {

@@ -314,7 +314,52 @@ struct Engine::Impl {
     struct ChainWorker {                                     // the context's chain threads: one by default, `workers` draw queued streams side by side
         std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
         std::deque<std::shared_ptr<BlindStream>> pending; bool quit = false;
+        uint32_t lanes = 1;                                  // streams one thread draws in lockstep (merlin.hpp strobe_rng_bulk64_x8); set before the threads start
+        // One thread, up to eight streams in lockstep: the sponges of eight proofs in the eight 64-bit lanes of ZMM registers cost a Zen 5 core
+        // 193 ns per draw of all eight against 152 ns for one alone (tools/diag/chain_lanes.py): a chain still takes 0.3 - 0.4 s, a core's chain
+        // THROUGHPUT goes up sixfold.  Streams join at 4,096-draw boundaries as they are queued and leave when they are complete or stopped.
+        static void run_lanes(ChainWorker *w) {
+            struct Lane { std::shared_ptr<BlindStream> b; TranscriptRng rng; uint64_t pos, up; };
+            std::vector<Lane> act;
+            auto upload = [](Lane &L, uint64_t to) {
+                if (to <= L.up) return;
+                BlindStream &b = *L.b;
+                const uint64_t k = L.up / BlindStream::UP;
+                (void)hipMemcpyAsync(b.d_raw + 64 * L.up, b.raw + 64 * L.up, (to - L.up) * 64, hipMemcpyHostToDevice, b.copy_st);
+                (void)hipEventRecord((*b.ev)[k], b.copy_st);
+                L.up = to;
+                b.uploaded_blocks.store(k + 1, std::memory_order_release);
+            };
+            for (;;) {
+                {   // take what is queued; wait only when there is nothing to draw
+                    std::unique_lock<std::mutex> lk(w->mu);
+                    if (act.empty()) { w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; }
+                    while (act.size() < w->lanes && !w->pending.empty()) {
+                        std::shared_ptr<BlindStream> b = w->pending.front(); w->pending.pop_front();
+                        b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
+                        (void)hipSetDevice(b->device);
+                        act.push_back(Lane{b, b->snaps[0], 0, 0});
+                    }
+                }
+                for (size_t k = 0; k < act.size();) {            // publish; retire what is complete or stopped
+                    Lane &L = act[k]; BlindStream &b = *L.b;
+                    if (L.pos) b.snaps[L.pos / BlindStream::SNAP] = L.rng;
+                    b.produced.store(L.pos, std::memory_order_release);
+                    if (L.pos >= b.max_draws || b.stop.load(std::memory_order_relaxed)) {
+                        upload(L, L.pos);
+                        b.finished.store(true, std::memory_order_release);
+                        act.erase(act.begin() + (ptrdiff_t)k);
+                    } else k++;
+                }
+                if (act.empty()) continue;
+                TranscriptRng *r[8]; uint8_t *dst[8];
+                for (size_t k = 0; k < act.size(); k++) { r[k] = &act[k].rng; dst[k] = act[k].b->raw + 64 * act[k].pos; }
+                TranscriptRng::fill_draws64_multi(r, dst, (uint32_t)act.size(), BlindStream::SNAP);
+                for (Lane &L : act) { L.pos += BlindStream::SNAP; if (L.pos % BlindStream::UP == 0) upload(L, L.pos); }
+            }
+        }
         static void run(ChainWorker *w) {
+            if (w->lanes > 1) { run_lanes(w); return; }
             for (;;) {
                 std::shared_ptr<BlindStream> b;
                 { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
@@ -344,7 +389,8 @@ struct Engine::Impl {
         }
     };
     std::unique_ptr<ChainWorker> chain;
-    uint32_t chain_workers = 1;                             // threads of the chain worker (bpg_ctx_set_chain_workers / BPG_CHAIN_WORKERS); alive streams <= workers + 1
+    uint32_t chain_workers = 1;                             // threads of the chain worker (bpg_ctx_set_chain_workers / BPG_CHAIN_WORKERS); alive streams <= workers * lanes + 1
+    uint32_t chain_lanes = 1;                               // streams each thread draws in lockstep (bpg_ctx_set_chain_lanes / BPG_CHAIN_LANES, 1..8)
     std::deque<std::shared_ptr<BlindStream>> blinds;        // alive streams, oldest first
     std::vector<std::shared_ptr<BlindStream>> slab_owner;   // last stream that wrote each pinned slab (workers + 1 slabs)
     std::vector<PinBuf> h_blind;
@@ -432,6 +478,7 @@ Engine::Engine(int device) : device_(device) {
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("BPG_CHAIN_LANES")) { int v = std::atoi(e); if (v >= 1 && v <= 8) impl_->chain_lanes = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_CHAIN_WORKERS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) impl_->chain_workers = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
@@ -1167,7 +1214,7 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     Impl &I = *impl_;
     if (max_multipliers == 0) { I.blind_cancel(); return; }
     using BS = Impl::BlindStream;
-    const size_t max_alive = (size_t)I.chain_workers + 1;
+    const size_t max_alive = (size_t)I.chain_workers * I.chain_lanes + 1;
     while (I.blinds.size() >= max_alive) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // the oldest gives way
     auto b = std::make_shared<BS>();
     Transcript T = after_commitments;
@@ -1199,7 +1246,7 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
     I.slab_owner[slot] = b;
     I.blinds.push_back(b);
-    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); (void)keccak_impl(); }
+    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); I.chain->lanes = I.chain_lanes; (void)keccak_impl(); }
     while (I.chain->th.size() < I.chain_workers) I.chain->th.emplace_back(Impl::ChainWorker::run, I.chain.get());
     { std::lock_guard<std::mutex> lk(I.chain->mu); I.chain->pending.push_back(b); }
     I.chain->cv.notify_one();
@@ -1208,6 +1255,11 @@ void Engine::set_chain_workers(uint32_t n) {
     if (n < 1 || n > 64) throw std::invalid_argument("chain workers: 1..64");
     impl_->chain_shutdown();                                  // streams in flight are dropped; threads restart with the next begin
     impl_->chain_workers = n;
+}
+void Engine::set_chain_lanes(uint32_t n) {
+    if (n < 1 || n > 8) throw std::invalid_argument("chain lanes: 1..8");
+    impl_->chain_shutdown();
+    impl_->chain_lanes = n;
 }
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
 int Engine::chain_cpu() const { return impl_->last_chain_cpu; }

@@ -49,6 +49,7 @@ public:
     void blinding_cancel();
     // threads of the context's chain worker: that many queued streams are drawn side by side, workers + 1 may be alive (default 1)
     void set_chain_workers(uint32_t n);
+    void set_chain_lanes(uint32_t n);        // streams each chain thread draws in lockstep (1..8; eight sponges in the lanes of ZMM registers)
     int chain_cpu() const;      // host core the chain worker last drew a stream on (-1: none yet); diagnostics for bench.py
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
     // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.

@@ -181,6 +181,67 @@ __attribute__((target("avx512f,avx512vl"))) static inline void strobe_rng_bulk64
     KX_STORE(s);
 }
 
+// EIGHT independent sponges at once: the same lanes-in-registers round body on ZMM registers, lane v of every register belonging to
+// sponge v.  On Zen 5 a 512-bit VPTERNLOGQ / VPROLQ issues at the rate of a 128-bit one (tools/diag/zen5_wide.cpp), so eight TranscriptRng
+// chains of eight different proofs cost one core about what one chain costs it - the serial chain of ONE proof gets no shorter, a core's
+// chain THROUGHPUT goes up eightfold.  Same bytes per sponge as strobe_rng_bulk64_xmm (tests/test_device_arith_host.py).
+#define KZ_X3(a, b, c) _mm512_ternarylogic_epi64(a, b, c, 0x96)
+#define KZ_CHI(a, b, c) _mm512_ternarylogic_epi64(a, b, c, 0xD2)
+#define KZ_RX(a, d, n) _mm512_rol_epi64(_mm512_xor_si512(a, d), n)
+#define KZ_GATHER(i) _mm512_set_epi64((long long)st[7][i], (long long)st[6][i], (long long)st[5][i], (long long)st[4][i], (long long)st[3][i], (long long)st[2][i], (long long)st[1][i], (long long)st[0][i])
+#define KZ_SCATTER(i, v) do { _mm512_store_si512(tmp, v); for (int l_ = 0; l_ < 8; l_++) st[l_][i] = tmp[l_]; } while (0)
+#define KZ_24_ROUNDS(RC) \
+    for (int r_ = 0; r_ < 24; r_++) { \
+        const __m512i c0 = KZ_X3(KZ_X3(a00, a05, a10), a15, a20), c1 = KZ_X3(KZ_X3(a01, a06, a11), a16, a21), \
+                      c2 = KZ_X3(KZ_X3(a02, a07, a12), a17, a22), c3 = KZ_X3(KZ_X3(a03, a08, a13), a18, a23), \
+                      c4 = KZ_X3(KZ_X3(a04, a09, a14), a19, a24); \
+        const __m512i d0 = _mm512_xor_si512(c4, _mm512_rol_epi64(c1, 1)), d1 = _mm512_xor_si512(c0, _mm512_rol_epi64(c2, 1)), \
+                      d2 = _mm512_xor_si512(c1, _mm512_rol_epi64(c3, 1)), d3 = _mm512_xor_si512(c2, _mm512_rol_epi64(c4, 1)), \
+                      d4 = _mm512_xor_si512(c3, _mm512_rol_epi64(c0, 1)); \
+        __m512i b0, b1, b2, b3, b4; \
+        b0 = _mm512_xor_si512(a00, d0); b1 = KZ_RX(a06, d1, 44); b2 = KZ_RX(a12, d2, 43); b3 = KZ_RX(a18, d3, 21); b4 = KZ_RX(a24, d4, 14); \
+        const __m512i n00 = _mm512_xor_si512(KZ_CHI(b0, b1, b2), _mm512_set1_epi64((long long)(RC)[r_])), \
+                      n01 = KZ_CHI(b1, b2, b3), n02 = KZ_CHI(b2, b3, b4), n03 = KZ_CHI(b3, b4, b0), n04 = KZ_CHI(b4, b0, b1); \
+        b0 = KZ_RX(a03, d3, 28); b1 = KZ_RX(a09, d4, 20); b2 = KZ_RX(a10, d0, 3); b3 = KZ_RX(a16, d1, 45); b4 = KZ_RX(a22, d2, 61); \
+        const __m512i n05 = KZ_CHI(b0, b1, b2), n06 = KZ_CHI(b1, b2, b3), n07 = KZ_CHI(b2, b3, b4), n08 = KZ_CHI(b3, b4, b0), n09 = KZ_CHI(b4, b0, b1); \
+        b0 = KZ_RX(a01, d1, 1); b1 = KZ_RX(a07, d2, 6); b2 = KZ_RX(a13, d3, 25); b3 = KZ_RX(a19, d4, 8); b4 = KZ_RX(a20, d0, 18); \
+        const __m512i n10 = KZ_CHI(b0, b1, b2), n11 = KZ_CHI(b1, b2, b3), n12 = KZ_CHI(b2, b3, b4), n13 = KZ_CHI(b3, b4, b0), n14 = KZ_CHI(b4, b0, b1); \
+        b0 = KZ_RX(a04, d4, 27); b1 = KZ_RX(a05, d0, 36); b2 = KZ_RX(a11, d1, 10); b3 = KZ_RX(a17, d2, 15); b4 = KZ_RX(a23, d3, 56); \
+        const __m512i n15 = KZ_CHI(b0, b1, b2), n16 = KZ_CHI(b1, b2, b3), n17 = KZ_CHI(b2, b3, b4), n18 = KZ_CHI(b3, b4, b0), n19 = KZ_CHI(b4, b0, b1); \
+        b0 = KZ_RX(a02, d2, 62); b1 = KZ_RX(a08, d3, 55); b2 = KZ_RX(a14, d4, 39); b3 = KZ_RX(a15, d0, 41); b4 = KZ_RX(a21, d1, 2); \
+        const __m512i n20 = KZ_CHI(b0, b1, b2), n21 = KZ_CHI(b1, b2, b3), n22 = KZ_CHI(b2, b3, b4), n23 = KZ_CHI(b3, b4, b0), n24 = KZ_CHI(b4, b0, b1); \
+        a00 = n00; a01 = n01; a02 = n02; a03 = n03; a04 = n04; a05 = n05; a06 = n06; a07 = n07; a08 = n08; a09 = n09; \
+        a10 = n10; a11 = n11; a12 = n12; a13 = n13; a14 = n14; a15 = n15; a16 = n16; a17 = n17; a18 = n18; a19 = n19; \
+        a20 = n20; a21 = n21; a22 = n22; a23 = n23; a24 = n24; \
+    }
+// `count` steady-state TranscriptRng draws (see strobe_rng_bulk64_xmm) for each of eight sponges st[v] -> dest[v]
+__attribute__((target("avx512f"))) static inline void strobe_rng_bulk64_x8(uint64_t *const st[8], uint8_t *const dest[8], size_t count,
+                                                                            uint64_t k8, uint64_t k9, uint64_t k20) {
+    alignas(64) uint64_t tmp[8];
+    alignas(64) uint64_t out[8][8];
+    __m512i a00 = KZ_GATHER(0), a01 = KZ_GATHER(1), a02 = KZ_GATHER(2), a03 = KZ_GATHER(3), a04 = KZ_GATHER(4), a05 = KZ_GATHER(5), a06 = KZ_GATHER(6),
+            a07 = KZ_GATHER(7), a08 = KZ_GATHER(8), a09 = KZ_GATHER(9), a10 = KZ_GATHER(10), a11 = KZ_GATHER(11), a12 = KZ_GATHER(12), a13 = KZ_GATHER(13),
+            a14 = KZ_GATHER(14), a15 = KZ_GATHER(15), a16 = KZ_GATHER(16), a17 = KZ_GATHER(17), a18 = KZ_GATHER(18), a19 = KZ_GATHER(19), a20 = KZ_GATHER(20),
+            a21 = KZ_GATHER(21), a22 = KZ_GATHER(22), a23 = KZ_GATHER(23), a24 = KZ_GATHER(24);
+    const __m512i x8 = _mm512_set1_epi64((long long)k8), x9 = _mm512_set1_epi64((long long)k9), x20 = _mm512_set1_epi64((long long)k20);
+    for (size_t i = 0; i < count; i++) {
+        a08 = _mm512_xor_si512(a08, x8); a09 = _mm512_xor_si512(a09, x9); a20 = _mm512_xor_si512(a20, x20);
+        KZ_24_ROUNDS(KECCAK_RC_XMM)
+        _mm512_store_si512(out[0], a00); _mm512_store_si512(out[1], a01); _mm512_store_si512(out[2], a02); _mm512_store_si512(out[3], a03);
+        _mm512_store_si512(out[4], a04); _mm512_store_si512(out[5], a05); _mm512_store_si512(out[6], a06); _mm512_store_si512(out[7], a07);
+        for (int v = 0; v < 8; v++) {                        // word j of sponge v is lane v of register j
+            uint64_t *o = reinterpret_cast<uint64_t *>(dest[v] + 64 * i);
+            for (int j = 0; j < 8; j++) o[j] = out[j][v];
+        }
+        a00 = a01 = a02 = a03 = a04 = a05 = a06 = a07 = _mm512_setzero_si512();
+    }
+    KZ_SCATTER(0, a00); KZ_SCATTER(1, a01); KZ_SCATTER(2, a02); KZ_SCATTER(3, a03); KZ_SCATTER(4, a04); KZ_SCATTER(5, a05); KZ_SCATTER(6, a06);
+    KZ_SCATTER(7, a07); KZ_SCATTER(8, a08); KZ_SCATTER(9, a09); KZ_SCATTER(10, a10); KZ_SCATTER(11, a11); KZ_SCATTER(12, a12); KZ_SCATTER(13, a13);
+    KZ_SCATTER(14, a14); KZ_SCATTER(15, a15); KZ_SCATTER(16, a16); KZ_SCATTER(17, a17); KZ_SCATTER(18, a18); KZ_SCATTER(19, a19); KZ_SCATTER(20, a20);
+    KZ_SCATTER(21, a21); KZ_SCATTER(22, a22); KZ_SCATTER(23, a23); KZ_SCATTER(24, a24);
+}
+static inline bool keccak_have_x8() { static const bool ok = __builtin_cpu_supports("avx512f"); return ok; }
+
 // Which one is fastest depends on the core (EPYC 9575F / Zen 5: lanes-in-XMM 154 ns, scalar 177 ns, planes-in-ZMM 228 ns, the
 // cross-lane permutes having a long latency there; Xeon: the vector forms win by more), so a ~2 ms calibration at first
 // use picks the implementation.  All three compute the same permutation (tests/test_host_logic.py); the choice never
@@ -214,6 +275,7 @@ static inline void keccak_f1600_host(uint64_t s[25]) {
 }
 #else
 static inline int keccak_impl() { return 0; }
+static inline bool keccak_have_x8() { return false; }
 static inline bool keccak_have_avx512() { return false; }
 static inline void keccak_f1600_host(uint64_t s[25]) { keccak_f1600_scalar(s); }
 #endif
@@ -282,6 +344,41 @@ public:
         }
         pos_ = 64; pos_begin_ = 0; cur_flags_ = FLAG_I | FLAG_A | FLAG_C;
     }
+    // `count` TranscriptRng draws for each of `lanes` (<= 8) independent sponges in lockstep: same bytes as rng_draws64 on each
+    static void rng_draws64_multi(Strobe128 *const s[], uint8_t *const dest[], uint32_t lanes, size_t count) {
+#if defined(__x86_64__)
+        if (lanes > 1 && lanes <= 8 && keccak_have_x8() && count > 1) {
+            // every sponge reaches the steady state (pos 64) through the generic operations: at most one draw each; all take the same number
+            size_t head = 0;
+            for (uint32_t v = 0; v < lanes; v++) if (s[v]->pos_ != 64) head = 1;
+            for (uint32_t v = 0; v < lanes; v++) for (size_t i = 0; i < head; i++) { const uint8_t l4[4] = {64, 0, 0, 0}; s[v]->meta_ad(l4, 4, false); s[v]->prf(dest[v] + 64 * i, 64, false); }
+            bool steady = true;
+            for (uint32_t v = 0; v < lanes; v++) steady = steady && s[v]->pos_ == 64;
+            if (steady) {
+                const uint64_t k8 = (0x12ULL << 8) | (64ULL << 16) | (65ULL << 48) | (0x07ULL << 56), k9 = 71ULL | (0x04ULL << 8), k20 = 0x80ULL << 56;
+                uint64_t idle_state[25]; alignas(64) static thread_local uint8_t idle_out[64 * 4096];
+                std::memset(idle_state, 0, sizeof idle_state);
+                uint64_t *st[8]; uint8_t *dst[8];
+                for (uint32_t v = 0; v < 8; v++) {
+                    if (v < lanes) { s[v]->st_[8] ^= s[v]->pos_begin_; st[v] = s[v]->st_; dst[v] = dest[v] + 64 * head; }
+                    else { st[v] = idle_state; dst[v] = idle_out; }
+                }
+                size_t left = count - head;
+                while (left) {                                   // idle lanes write into a 4096-draw scratch: chunk the call accordingly
+                    const size_t chunk = left < 4096 ? left : 4096;
+                    strobe_rng_bulk64_x8(st, dst, chunk, k8, k9, k20);
+                    for (uint32_t v = 0; v < lanes; v++) dst[v] += 64 * chunk;
+                    left -= chunk;
+                }
+                for (uint32_t v = 0; v < lanes; v++) { s[v]->pos_ = 64; s[v]->pos_begin_ = 0; s[v]->cur_flags_ = FLAG_I | FLAG_A | FLAG_C; }
+                return;
+            }
+            for (uint32_t v = 0; v < lanes; v++) s[v]->rng_draws64(dest[v] + 64 * head, count - head);
+            return;
+        }
+#endif
+        for (uint32_t v = 0; v < lanes; v++) s[v]->rng_draws64(dest[v], count);
+    }
     void export_state(uint8_t out[203]) const { std::memcpy(out, st_, 200); out[200] = pos_; out[201] = pos_begin_; out[202] = cur_flags_; }
     void import_state(const uint8_t in[203]) { std::memcpy(st_, in, 200); pos_ = in[200]; pos_begin_ = in[201]; cur_flags_ = in[202]; }
 private:
@@ -319,6 +416,11 @@ public:
     explicit TranscriptRng(const Strobe128 &s) : s_(s) {}
     void fill_bytes(uint8_t *dest, size_t n) { uint8_t l4[4]; le32(l4, n); s_.meta_ad(l4, 4, false); s_.prf(dest, n, false); }
     void fill_draws64(uint8_t *dest, size_t count) { s_.rng_draws64(dest, count); }      // count x fill_bytes(.., 64), bulk
+    static void fill_draws64_multi(TranscriptRng *const r[], uint8_t *const dest[], uint32_t lanes, size_t count) {      // lanes <= 8 generators in lockstep
+        Strobe128 *s[8];
+        for (uint32_t v = 0; v < lanes && v < 8; v++) s[v] = &r[v]->s_;
+        Strobe128::rng_draws64_multi(s, dest, lanes, count);
+    }
     Scalar random_scalar() { uint8_t b[64]; fill_bytes(b, 64); return Scalar::from_wide(b); }
     static void le32(uint8_t b[4], size_t n) { b[0] = (uint8_t)n; b[1] = (uint8_t)(n >> 8); b[2] = (uint8_t)(n >> 16); b[3] = (uint8_t)(n >> 24); }
 private:

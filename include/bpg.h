@@ -189,6 +189,11 @@ bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[BPG_T
  * ahead of the proof it is proving and the GPU, not one host core's Keccak chain, sets the pace.  Streams in flight are dropped by the call.
  * Each alive stream pins 128 bytes per multiplier of host memory. */
 bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers);
+/* streams EACH chain thread draws in lockstep, 1..8 (default 1): with AVX-512 the sponges of up to eight queued streams sit in the 64-bit lanes of ZMM
+ * registers and cost one core about what one costs it (EPYC 9575F: 193 ns per draw of all eight against 152 ns for one), so one thread keeps
+ * up to eight chains going - a chain alone gets ~25 % slower, a core's chain throughput six times higher; workers * lanes + 1 streams may be alive.
+ * Streams in flight are dropped by this call, like bpg_ctx_set_chain_workers. */
+bpg_status bpg_ctx_set_chain_lanes(bpg_ctx *ctx, uint32_t lanes);
 int32_t bpg_chain_cpu(bpg_ctx *ctx);   /* diagnostics: host core the chain worker last ran on, -1 = no stream drawn yet */
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags,
                             uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);
@@ -244,6 +249,10 @@ bpg_status bpg_be_to_scalars(const uint8_t *be, uint64_t len, uint8_t *out, uint
  * `skip` draws through the generic STROBE operations; bulk != 0 uses the prover's in-register bulk path. Same bytes either way. */
 bpg_status bpg_rng_draws(const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, const uint8_t rng_seed[32],
                          uint64_t skip, uint64_t count, int32_t bulk, uint8_t *out);
+/* the same for `lanes` (1..8) generators with seeds rng_seeds[lanes][32] drawn in lockstep (csrc/host/merlin.hpp: eight sponges in the lanes of ZMM
+   registers); lane v skips skip[v] draws first; out = [lanes][count][64] */
+bpg_status bpg_rng_draws_multi(const uint8_t transcript_state[203], uint64_t m, const uint8_t *v_blinding, uint32_t lanes, const uint8_t *rng_seeds,
+                               const uint64_t *skip, uint64_t count, uint8_t *out);
 /* host Keccak-f[1600] self-check: runs the scalar and (when the CPU has AVX-512F+VL) both vector implementations on `rounds` chained
  * states derived from seed; *impl_out = the active one (0 scalar, 1 planes-in-ZMM, 2 lanes-in-XMM; chosen by a start-up calibration).
  * Fails with BPG_ERR_INTERNAL on a mismatch. */

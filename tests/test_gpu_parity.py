@@ -649,7 +649,7 @@ def test_speculative_blinding_stream_changes_no_byte(ctx):
 
 
 def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
-    """The chain worker draws queued streams one at a time, in order; up to two stay alive (bench.py's sequence: begin(i+1), prove(i)).
+    """The chain worker draws queued streams one at a time, in order; up to two stay alive (one proving stream's sequence: begin(i+1), prove(i)).
     Every proof of the sequence equals the stand-alone proof of the same seed; a third begin retires the oldest stream; proofs whose
     stream was retired, never queued or queued out of order still come out byte-identical."""
     a = workloads.mimc_preimage(ctx, nbytes=200, seed=3)               # n = 6,804: 2n crosses three snapshots of 4,096 draws
@@ -700,6 +700,33 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     finally:
         ctx.set_chain_workers(1)                                 # drops what is still queued
     assert res.prove(state, inst.v_blinding, seeds[3], 0)[0] == alone[3]
+    # one chain thread, several streams in lockstep (bpg_ctx_set_chain_lanes: the sponges of up to eight queued streams in the lanes of ZMM
+    # registers): streams join and leave at snapshot boundaries; circuits of different sizes share a thread; same bytes throughout
+    b2 = workloads.mimc_preimage(ctx, nbytes=500, seed=9)              # another n: its streams run longer than the others'
+    inst2, state2 = b2.prover.instance(), b2.transcript.state
+    ctx.gens_ensure(b2.gens_capacity)
+    res2 = ctx.upload(inst2)
+    alone2 = [res2.prove(state2, inst2.v_blinding, s, 0)[0] for s in seeds[:2]]
+    for lanes in (2, 5, 8):
+        ctx.set_chain_lanes(lanes)
+        try:
+            queued, got = 0, []
+            for k, s in enumerate(seeds):
+                while queued < len(seeds) and queued <= k + lanes - 1:
+                    ctx.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                    queued += 1
+                got.append(res.prove(state, inst.v_blinding, s, 0)[0])
+            assert got == alone, lanes
+            ctx.blinding_begin(state2, inst2.v_blinding, seeds[0], inst2.n)      # mixed sizes in one lockstep group
+            ctx.blinding_begin(state, inst.v_blinding, seeds[1], inst.n)
+            ctx.blinding_begin(state2, inst2.v_blinding, seeds[1], inst2.n)
+            assert res.prove(state, inst.v_blinding, seeds[1], 0)[0] == alone[1]
+            assert res2.prove(state2, inst2.v_blinding, seeds[1], 0)[0] == alone2[1]
+            assert res2.prove(state2, inst2.v_blinding, seeds[0], 0)[0] == alone2[0]
+        finally:
+            ctx.set_chain_lanes(1)
+    assert res.prove(state, inst.v_blinding, seeds[2], 0)[0] == alone[2]
+    res2.free()
     res.free()
 
 

@@ -187,6 +187,28 @@ def test_bulk_rng_draws_match_generic_strobe_path_and_oracle():
     assert got == b"".join(want)
 
 
+def test_lockstep_rng_draws_match_the_single_generator():
+    """Eight TranscriptRng generators of eight different proofs drawn in lockstep (one sponge per 64-bit lane of ZMM registers, merlin.hpp
+    strobe_rng_bulk64_x8; falls back to one after the other without AVX-512): every lane gives the bytes of its own generic STROBE path, from
+    different starting positions, for any number of lanes."""
+    import ctypes as C
+    t = bpg.Transcript(b"rng-lanes")
+    t.append_message(b"x", b"z" * 11)
+    vb = b"".join(bytes([i + 3]) + bytes(31) for i in range(2))
+    count = 700
+    for lanes in (1, 2, 5, 8):
+        seeds = b"".join(bytes([17 * v + 1]) * 32 for v in range(lanes))
+        skips = [(3 * v) % 4 for v in range(lanes)]                       # some lanes start at the steady position, some do not
+        out = C.create_string_buffer(lanes * 64 * count)
+        rc = bpg.lib().bpg_rng_draws_multi(t.state, C.c_uint64(2), vb, C.c_uint32(lanes), seeds, (C.c_uint64 * lanes)(*skips), C.c_uint64(count), out)
+        assert rc == 0, bpg.lib().bpg_last_error()
+        for v in range(lanes):
+            ref = C.create_string_buffer(64 * count)
+            rc = bpg.lib().bpg_rng_draws(t.state, C.c_uint64(2), vb, seeds[32 * v:32 * v + 32], C.c_uint64(skips[v]), C.c_uint64(count), C.c_int32(0), ref)
+            assert rc == 0
+            assert out.raw[v * 64 * count:(v + 1) * 64 * count] == ref.raw, (lanes, v)
+
+
 def test_or_conjunction_assembly_counts_on_the_verifier_side():
     """src/or/or_conjunction.rs:4-38 with the recording buffer of src/cs_buffer.rs: the clauses' multipliers are replayed into the
     parent, then one product chain per element of the Cartesian product of the clauses' explicit constraints.
