@@ -235,7 +235,8 @@ struct Engine::Impl {
         auto it = shared->wide.find(M0);
         if (it != shared->wide.end()) return it->second.as<ge_pniels>();
         DevBuf table, bases8;
-        table.ensure(bytes); bases8.ensure((size_t)2 * M0 * TT8_WINDOWS * sizeof(ge_ext));
+        try { table.ensure(bytes); bases8.ensure((size_t)2 * M0 * TT8_WINDOWS * sizeof(ge_ext)); }
+        catch (const std::exception &) { (void)hipGetLastError(); table.release(); bases8.release(); return nullptr; }      // no room: the 4-bit tables do
         BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
         BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
         HIPCHK(hipGetLastError());
@@ -261,8 +262,18 @@ struct Engine::Impl {
         const uint32_t key = eff_wnaf | (eff_parts << 8);
         auto it = shared->odd.find(key);
         if (it != shared->odd.end()) { gens_odd = it->second; return; }
+        DevBuf odd;
+        for (;;) {   // a device that cannot spare the tables of this profile (other tenants) gets the next smaller one
+            try { odd.ensure(table_bytes(eff_wnaf, eff_parts)); break; }
+            catch (const std::exception &) {
+                (void)hipGetLastError();
+                if (eff_parts > 1) eff_parts /= 2; else if (eff_wnaf > 3) eff_wnaf--; else throw;
+                auto it2 = shared->odd.find(eff_wnaf | (eff_parts << 8));
+                if (it2 != shared->odd.end()) { gens_odd = it2->second; return; }
+            }
+        }
+        const uint32_t key_built = eff_wnaf | (eff_parts << 8);
         const uint32_t NM = 1u << (eff_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
-        DevBuf odd; odd.ensure(((size_t)eff_parts * NM - 1) * cnt * sizeof(ge_niels));
         scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
         DevBuf dbl, base; dbl.ensure((size_t)cnt * sizeof(ge_ext));
         if (eff_parts > 1) base.ensure((size_t)cnt * sizeof(ge_ext));
@@ -283,7 +294,7 @@ struct Engine::Impl {
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         dbl.release(); base.release();
-        shared->odd[key] = odd;
+        shared->odd[key_built] = odd;
         gens_odd = odd;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
