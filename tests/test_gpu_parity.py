@@ -461,6 +461,37 @@ def test_fold_group_sizes_above_the_tail(ctx, blocks, N):
     res.free()
 
 
+def test_fold_profiles_agree_at_half_a_million_multipliers(monkeypatch):
+    """At N = 2^19 the DEFAULT schedule takes the width-w NAF fold (the small cases force it with BPG_FOLD_SPLIT=0): the serving profile (width 8,
+    scalars cut in four), the one-shot profile of the file drivers (width 6, unsplit), a two-part split and the register kernels (no tables) must
+    give the same proof, which the GPU verifier accepts and rejects when tampered.  (bench.py compares the serving profile with the oracle
+    prover at 2^20 in every default run.)"""
+    proofs = {}
+    for name, env in (("serving", {}), ("one-shot", {"BPG_FOLD_WNAF": "6", "BPG_FOLD_PARTS": "1"}), ("two parts", {"BPG_FOLD_WNAF": "7", "BPG_FOLD_PARTS": "2"}),
+                      ("registers", {"BPG_FOLD_WNAF": "0"})):
+        for k in ("BPG_FOLD_WNAF", "BPG_FOLD_PARTS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = bpg.Context(0)
+        try:
+            a = workloads.merkle_full_tree(c, leaves=256, seed=5)
+            inst = a.prover.instance()
+            assert a.gens_capacity == 1 << 19
+            c.gens_ensure(a.gens_capacity)
+            res = c.upload(inst)
+            proofs[name] = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)[0]
+            if name == "serving":
+                coms = b"".join(a.commitments)
+                assert res.verify(a.transcript.state, coms, proofs[name]) == 0
+                bad = bytearray(proofs[name]); bad[len(bad) // 2] ^= 1
+                assert res.verify(a.transcript.state, coms, bytes(bad)) != 0
+            res.free()
+        finally:
+            c.close()
+    assert len(set(proofs.values())) == 1, {k: v[:8].hex() for k, v in proofs.items()}
+
+
 def test_expanded_blinding_dialect_matches_oracle_and_verifies(ctx):
     """BPG_FLAG_EXPANDED_BLINDING (opt-in, not upstream's derivation of s_L, s_R): same bytes as the oracle's independent
     restatement (SHAKE256 over one TranscriptRng draw), accepted by both verifiers, different from the default dialect."""
