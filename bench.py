@@ -53,6 +53,8 @@ def parse_args(argv=None):
     ap.add_argument("--streams", type=int, default=14, help="proving streams per GPU for the headline (at most one per step): that many engine contexts (own HIP stream, "
                     "proving thread, share of the chain workers; generator tables shared) take the steps round-robin. With one chain thread per stream every proof "
                     "runs A_I, A_O and most of S under its own chain, so the GPU works through the 0.3 s the first chains take")
+    ap.add_argument("--chain-lanes", type=int, default=1, help="streams each chain thread draws in lockstep (bpg_ctx_set_chain_lanes, 1..8: the sponges of several proofs in the "
+                    "lanes of ZMM registers): with 8 a chain takes 27 %% longer and a core draws six times as many; the headline keeps 1 (shortest chains)")
     ap.add_argument("--no-prefetch", action="store_true", help="draw every chain inside its own prove call (round-1 behaviour): the GPU idles while the host draws")
     ap.add_argument("--batch", type=int, default=8, help="strong-scaling leg: this many independent proofs in total, sharded round-robin over the ranks (0 = skip)")
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
@@ -315,6 +317,9 @@ def run_rank(args):
     n_streams = max(1, min(args.streams, args.steps))         # more streams than steps would only allocate
     lane_workers = max(1, -(-max(1, args.chain_workers) // n_streams))       # chain threads per proving stream
     ctx.set_chain_workers(lane_workers)
+    lanes_per_thread = max(1, min(8, args.chain_lanes))
+    if lanes_per_thread > 1:
+        ctx.set_chain_lanes(lanes_per_thread)
     t0 = time.perf_counter()
     a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=None if rank == 0 else rank)
     inst = a.prover.instance()
@@ -335,6 +340,8 @@ def run_rank(args):
     for _ in range(n_streams - 1):
         c2 = bpg.Context(device_index)
         c2.set_chain_workers(lane_workers)
+        if lanes_per_thread > 1:
+            c2.set_chain_lanes(lanes_per_thread)
         c2.gens_ensure(a.gens_capacity)
         extra_lanes.append((c2, c2.upload(inst)))
 
@@ -383,7 +390,7 @@ def run_rank(args):
         the next `ahead` proofs are queued on the chain worker before proof i is proved (bpg_blinding_begin: same bytes as drawing them inside
         prove); every chain of the sequence starts and ends inside it."""
         c_, r_ = lanes[lane]
-        ahead = lane_workers if ahead is None else ahead
+        ahead = lane_workers * lanes_per_thread if ahead is None else ahead
         outs = []
         queued = 0
         for i, s in enumerate(seeds):
