@@ -60,7 +60,10 @@ def parse_args(argv=None):
     ap.add_argument("--kernel-profile", action="store_true", help="list every kernel's HIP-event total of one untimed proof in the line")
     ap.add_argument("--headline-only", action="store_true", help="only the warmup and timed steps (no verify / expanded-blinding / in-flight / batch / CPU legs): "
                     "the process then launches nothing but the headline's kernels, which is what the rocprofv3 passes of tools/profile_round.sh want")
-    ap.add_argument("--in-flight", type=int, default=12, help="throughput leg: independent proofs in flight on ONE GPU, one engine context + host thread each (0 = skip)")
+    ap.add_argument("--in-flight", type=int, default=6, help="throughput leg: proving streams (engine contexts, one proving thread each) on ONE GPU (0 = skip)")
+    ap.add_argument("--in-flight-workers", type=int, default=1, help="throughput leg: chain threads per context")
+    ap.add_argument("--in-flight-lanes", type=int, default=8, help="throughput leg: streams per chain thread in lockstep (1..8)")
+    ap.add_argument("--in-flight-steps", type=int, default=24, help="throughput leg: proofs per context")
     ap.add_argument("--in-flight-only", action="store_true", help="only the throughput leg (for profiling the concurrent kernel mix)")
     return ap.parse_args(argv)
 
@@ -186,7 +189,7 @@ def cpu_baseline(ctx, bpg, workloads, leaves, headline):
             "seconds": dt, "library": os.path.basename(lib_used), "full_size": leaves == 512}
 
 
-def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, steps):
+def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, steps, workers=1, lanes=1, restore_workers=1):
     """Throughput figure (never `value`): B independent proofs in flight on one GPU, one engine context + host thread each.
     The serial TranscriptRng chain of one proof then overlaps the kernels of the others."""
     import threading
@@ -195,6 +198,9 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
         c = bpg.Context(device)
         c.gens_ensure(capacity)
         ctxs.append(c); ress.append(c.upload(inst))
+    for c in ctxs:
+        c.set_chain_workers(workers); c.set_chain_lanes(lanes)
+    ahead = workers * lanes                                  # chains queued beyond the proof being proved (workers * lanes + 1 streams may be alive)
     start = threading.Barrier(n_ctx + 1)
     errs, done_at = [], []
 
@@ -206,10 +212,11 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
             # each context sequences its proofs as the headline does: the chain of its next proof is queued on its chain worker before the
             # current one is proved; under load a proof waits for the GPU longer than a chain takes, so the chain is complete when its
             # proof starts and A_I, A_O, S go through one multiscalar pass instead of four
-            ctxs[k].blinding_begin(state, inst.v_blinding, seeds[0], inst.n)
+            queued = 0
             for i in range(steps):
-                if i + 1 < steps:
-                    ctxs[k].blinding_begin(state, inst.v_blinding, seeds[i + 1], inst.n)
+                while queued < steps and queued <= i + ahead:
+                    ctxs[k].blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                    queued += 1
                 ress[k].prove(state, inst.v_blinding, seeds[i], 0)
                 done_at.append(time.perf_counter())
         except Exception as e:      # noqa: BLE001
@@ -230,15 +237,18 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
         r.free()
     for c in ctxs[1:]:
         c.close()
+    ctx0.set_chain_lanes(1); ctx0.set_chain_workers(max(1, restore_workers))
     if errs:
         raise RuntimeError(errs[0])
-    # all contexts start their first chain together, so the GPU idles for the first ~0.3 s of the run: the sustained rate is taken between the
-    # first and the last completion (proofs finished after the first one / the time that took); the plain wall figure is kept beside it
+    # all contexts start their first chains together, so nothing completes for the first 0.3 - 0.4 s and the first proofs of every context then
+    # complete in a bunch: the sustained rate is taken from the completion that follows that bunch (one proof per context) to the last one
     done_at.sort()
-    sustained = (len(done_at) - 1) / (done_at[-1] - done_at[0]) if len(done_at) > 1 and done_at[-1] > done_at[0] else n_ctx * steps / dt
+    skip = min(n_ctx, len(done_at) - 2) if len(done_at) > 2 else 0
+    sustained = (len(done_at) - 1 - skip) / (done_at[-1] - done_at[skip]) if len(done_at) > skip + 1 and done_at[-1] > done_at[skip] else n_ctx * steps / dt
     return {"proofs_in_flight": n_ctx, "proofs": n_ctx * steps, "seconds": dt, "value": inst.q * sustained, "ms_per_proof": 1e3 / sustained,
             "unit": "constraints/s", "whole_run": {"value": inst.q * n_ctx * steps / dt, "ms_per_proof": dt / (n_ctx * steps) * 1e3},
-            "rate": "proofs completed after the first completion / time from the first to the last completion"}
+            "host_threads": {"chain": n_ctx * workers, "lanes_per_chain_thread": lanes, "proving": n_ctx},
+            "rate": "proofs completed after the first %d completions / time from that completion to the last" % skip}
 
 
 def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
@@ -426,7 +436,8 @@ def run_rank(args):
 
     if args.in_flight_only:
         res.prove(state, inst.v_blinding, seed_for(999), 0)
-        out = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, max(args.in_flight, 2), max(2, args.steps))
+        out = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, max(args.in_flight, 2), max(2, args.in_flight_steps),
+                                   workers=max(1, args.in_flight_workers), lanes=max(1, min(8, args.in_flight_lanes)))
         if rank == 0:
             print(json.dumps({"in_flight": out}), flush=True)
         return
@@ -512,7 +523,8 @@ def run_rank(args):
         rate, err = 0.0, None
         try:
             barrier()
-            t = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, n_if, 4)
+            t = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, n_if, max(2, args.in_flight_steps // 2),
+                                     workers=max(1, args.in_flight_workers), lanes=max(1, min(8, args.in_flight_lanes)), restore_workers=args.chain_workers)
             rate = 1e3 / t["ms_per_proof"]
         except Exception as e:      # noqa: BLE001 - secondary: a rank that fails contributes nothing, the collectives below still match
             err = repr(e)
@@ -521,8 +533,8 @@ def run_rank(args):
         failed = allreduce(0.0 if err is None else 1.0, dist.ReduceOp.SUM)
         multi_thr = {"proofs_in_flight_per_gpu": n_if, "value": float(inst.q) * total, "unit": "constraints/s", "proofs_per_s": total,
                      "slowest_rank_proofs_per_s": slowest if slowest < 1e29 else 0.0, "ranks_failed": int(failed), "error_rank0": err,
-                     "note": "sum over the ranks of each GPU's sustained rate with independent proofs in flight (one context, chain worker and host thread "
-                             "per proof in flight); not the headline"}
+                     "note": "sum over the ranks of each GPU's sustained rate (proving streams per GPU as given, one chain thread with --in-flight-lanes lanes "
+                             "each); not the headline"}
 
     if rank != 0:
         if dist is not None:
@@ -714,9 +726,12 @@ def run_rank(args):
         out["kernel_ms"] = {k: round(v["total_ms"], 3) for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])}
     if world == 1 and args.in_flight > 1 and not args.headline_only:
         try:
-            thr = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, args.in_flight, 6)
-            thr["note"] = ("independent proofs in flight on ONE GPU, one engine context and host thread each: the chains of the proofs run on %d host cores and the "
-                           "GPU is the bound; not the headline" % args.in_flight)
+            thr = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, args.in_flight, max(2, args.in_flight_steps),
+                                       workers=max(1, args.in_flight_workers), lanes=max(1, min(8, args.in_flight_lanes)), restore_workers=args.chain_workers)
+            thr["note"] = ("sustained rate of ONE GPU over a long sequence: %d proving streams (engine contexts), each with %d chain thread(s) that draw(s) up to %d "
+                           "queued chains in lockstep (bpg_ctx_set_chain_lanes) - the chains are ready before their proofs start, so A_I, A_O, S go through one "
+                           "multiscalar pass and the GPU is the bound; not the headline"
+                           % (args.in_flight, max(1, args.in_flight_workers), max(1, min(8, args.in_flight_lanes))))
             if gpu_ms_per_proof:
                 thr["kernel_ms_per_proof_alone"] = gpu_ms_per_proof
                 thr["gpu_time_fraction"] = gpu_ms_per_proof / thr["ms_per_proof"]

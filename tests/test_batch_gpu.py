@@ -101,7 +101,7 @@ def test_bench_spawns_its_own_ranks():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "8", "--batch", "4",
-                        "--no-cpu-baseline", "--in-flight", "2"], env=env, capture_output=True, text=True, timeout=900)
+                        "--no-cpu-baseline", "--in-flight", "2", "--in-flight-steps", "4"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

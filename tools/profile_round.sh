@@ -31,8 +31,8 @@ if has stats; then
     # the same kernels alone on the GPU: one proving stream, one chain thread (the `isolated` figures of the bench line, the round-1 command)
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_single" -o "$tag" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 5 --warmup 2 > "$out/${tag}_bench_single_under_rocprof.json" 2> "$out/${tag}_stats_single.err") || { echo "single-stream stats pass failed"; tail -5 "$out/${tag}_stats_single.err"; exit 1; }
     echo "single-stream stats done"
-    # the concurrent mix of the throughput leg: 12 proofs in flight on 12 streams, kernels of different proofs share the CUs
-    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight 12 --steps 6 > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
+    # the concurrent mix of the throughput leg (6 proving streams, one chain thread with 8 lanes each, 24 proofs per stream): kernels of different proofs share the CUs
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats_inflight" -o "$tag" -- python3 "$root/bench.py" --in-flight-only > "$out/${tag}_bench_inflight_under_rocprof.json" 2> "$out/${tag}_stats_inflight.err") || { echo "in-flight stats pass failed"; tail -5 "$out/${tag}_stats_inflight.err"; exit 1; }
     echo "in-flight stats done"
 fi
 if has pmc; then
