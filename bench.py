@@ -319,6 +319,23 @@ def run_rank(args):
         dist = None
         device_index = 0
     placement = pin_near_gpu(torch, device_index)          # before the library creates its threads
+    # a chain thread needs a core to itself: where the ranks of this host leave a rank fewer cores than --chain-workers + 2, draw fewer chains side
+    # by side rather than share cores (an 8-GPU host with 128 cores gives each rank 16: the default 14 fits)
+    try:
+        cores_here = placement.get("cores_allowed") or max(1, len(os.sched_getaffinity(0)) // 2)
+        sharing = 1
+        if dist is not None:
+            nodes = [None] * world
+            dist.all_gather_object(nodes, placement.get("numa_node"))
+            sharing = max(1, sum(1 for x in nodes if x == placement.get("numa_node"))) if placement.get("pinned") else world
+        fit = max(2, cores_here // sharing - 2)
+        if args.chain_workers > fit:
+            log("rank %d: %d cores for %d rank(s) here: --chain-workers %d -> %d" % (rank, cores_here, sharing, args.chain_workers, fit))
+            args.chain_workers = fit
+            args.streams = min(args.streams, fit)
+        placement["cores_per_rank"] = cores_here // sharing
+    except Exception as e:      # noqa: BLE001 - sizing is an optimisation
+        placement["sizing_error"] = repr(e)
 
     import bulletproofs_gadgets_amd as bpg
     from bulletproofs_gadgets_amd import workloads
