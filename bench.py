@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 METRIC = "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU"
+ENGINE = {"profile": "serving", "blocking_sync": True}       # bpg_config of every engine context (include/bpg.h bpg_ctx_create_ex)
 
 
 def log(*a):
@@ -195,7 +196,7 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
     import threading
     ctxs, ress = [ctx0], [res0]
     for _ in range(n_ctx - 1):
-        c = bpg.Context(device)
+        c = bpg.Context(device, **ENGINE)
         c.gens_ensure(capacity)
         ctxs.append(c); ress.append(c.upload(inst))
     for c in ctxs:
@@ -285,9 +286,9 @@ def run_rank(args):
     # the throughput leg runs a dozen engine streams: 8 hardware queues instead of the runtime's default 4 measured 8 % more proofs/s
     # (tools/diag/exp1.sh); read by the HIP runtime at initialisation, so set before torch / the library load it
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    # proving threads sleep in their stream waits instead of spinning (hipDeviceScheduleBlockingSync, read by the engine at context creation):
-    # with a dozen of them beside a dozen chain threads the spinning costs the chains their cores (measured: 51 -> 54.5 M constraints/s at 14 streams)
-    os.environ.setdefault("BPG_SYNC_BLOCKING", "1")
+    # every context of this benchmark is created with bpg_ctx_create_ex (ENGINE below): the SERVING profile (a long-lived prover: 51.5 GB of fold
+    # tables per device, built once) and blocking stream waits - proving threads sleep instead of spinning; with a dozen of them beside a dozen
+    # chain threads the spinning costs the chains their cores (measured: 51 -> 54.5 M constraints/s at 14 streams)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -340,7 +341,7 @@ def run_rank(args):
     import bulletproofs_gadgets_amd as bpg
     from bulletproofs_gadgets_amd import workloads
     from bulletproofs_gadgets_amd.batch import gather_proofs, shard_indices
-    ctx = bpg.Context(device_index)
+    ctx = bpg.Context(device_index, **ENGINE)
     n_streams = max(1, min(args.streams, args.steps))         # more streams than steps would only allocate
     lane_workers = max(1, -(-max(1, args.chain_workers) // n_streams))       # chain threads per proving stream
     ctx.set_chain_workers(lane_workers)
@@ -365,7 +366,7 @@ def run_rank(args):
     prefetch = not args.no_prefetch
     extra_lanes = []
     for _ in range(n_streams - 1):
-        c2 = bpg.Context(device_index)
+        c2 = bpg.Context(device_index, **ENGINE)
         c2.set_chain_workers(lane_workers)
         if lanes_per_thread > 1:
             c2.set_chain_lanes(lanes_per_thread)

@@ -47,6 +47,27 @@ class Timings(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class Config(C.Structure):
+    """bpg_config (include/bpg.h): zero / -1 / None fields fall back to the BPG_* environment variable, then to the profile's default."""
+    _fields_ = [("struct_size", C.c_uint32), ("profile", C.c_uint32), ("table_budget_gb", C.c_double), ("chain_workers", C.c_uint32),
+                ("chain_lanes", C.c_uint32), ("blocking_sync", C.c_int32), ("gens_cache_dir", C.c_char_p)]
+
+
+PROFILE_DEFAULT, PROFILE_ONESHOT, PROFILE_SERVING = 0, 1, 2
+_PROFILES = {None: 0, "default": 0, "oneshot": 1, "one-shot": 1, "serving": 2, 0: 0, 1: 1, 2: 2}
+
+
+def make_config(profile=None, table_budget_gb=None, chain_workers=None, chain_lanes=None, blocking_sync=None, gens_cache_dir=None):
+    cfg = Config()
+    cfg.struct_size = C.sizeof(Config)
+    cfg.profile = _PROFILES[profile]
+    cfg.table_budget_gb = float(table_budget_gb or 0)
+    cfg.chain_workers, cfg.chain_lanes = int(chain_workers or 0), int(chain_lanes or 0)
+    cfg.blocking_sync = -1 if blocking_sync is None else int(bool(blocking_sync))
+    cfg.gens_cache_dir = os.fsencode(gens_cache_dir) if gens_cache_dir else None
+    return cfg
+
+
 class _Term(C.Structure):
     _pack_ = 1
     _fields_ = [("var", C.c_uint32), ("coeff", C.c_uint8 * 32)]
@@ -199,9 +220,20 @@ def _lc_array(lcs):
 class Context:
     """One GPU: PedersenGens (fixed bases) + the BulletproofGens tables resident in HBM."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, profile=None, **config):
+        """bpg_ctx_create(device) - the one-shot profile - or, with any of profile="serving" | "oneshot", table_budget_gb, chain_workers,
+        chain_lanes, blocking_sync, gens_cache_dir given, bpg_ctx_create_ex with that bpg_config."""
         self._h = C.c_void_p()
-        _chk(lib().bpg_ctx_create(C.c_int32(device), C.byref(self._h)))
+        if profile is None and not config:
+            _chk(lib().bpg_ctx_create(C.c_int32(device), C.byref(self._h)))
+        else:
+            cfg = make_config(profile, **config)
+            _chk(lib().bpg_ctx_create_ex(C.c_int32(device), C.byref(cfg), C.byref(self._h)))
+
+    def table_bytes(self):
+        """bpg_table_bytes: precomputed generator multiples this process holds on the context's device."""
+        lib().bpg_table_bytes.restype = C.c_uint64
+        return int(lib().bpg_table_bytes(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -317,9 +349,10 @@ class ProverPool:
     """bpg_pool_*: `workers` engine contexts + host threads on one GPU that prove a batch of independent instances concurrently (the
     serial TranscriptRng chain of one proof overlaps the kernels of the others). Same bytes as proving the items one by one."""
 
-    def __init__(self, device: int = 0, workers: int = 8, gens_capacity: int = 0):
+    def __init__(self, device: int = 0, workers: int = 8, gens_capacity: int = 0, profile=None, **config):
         self._h = C.c_void_p()
-        _chk(lib().bpg_pool_create(C.c_int32(device), C.c_uint32(workers), C.c_uint64(gens_capacity), C.byref(self._h)))
+        cfg = make_config(profile, **config) if (profile is not None or config) else None
+        _chk(lib().bpg_pool_create_ex(C.c_int32(device), C.c_uint32(workers), C.c_uint64(gens_capacity), C.byref(cfg) if cfg is not None else None, C.byref(self._h)))
         self.workers = workers
 
     def prove_batch(self, items):

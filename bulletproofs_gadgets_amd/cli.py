@@ -444,9 +444,7 @@ def main(argv=None):
     if len(argv) != 2 or argv[0] not in ("prover", "verifier"):
         print(__doc__)
         return 2
-    # a one-shot run makes ONE proof: the small fold tables instead of the serving profile (csrc/cli_main.cpp does the same)
-    import os
-    os.environ.setdefault("BPG_FOLD_WNAF", "6"); os.environ.setdefault("BPG_FOLD_PARTS", "1"); os.environ.setdefault("BPG_TT_WIDE_GB", "0")
+    # a run makes ONE proof per stem: Context()'s default, the one-shot profile (csrc/cli_main.cpp does the same)
     if argv[0] == "prover":
         prover(argv[1])
         return 0

@@ -145,9 +145,26 @@ const char *bpg_strerror(bpg_status s) {
 }
 const char *bpg_last_error(void) { return g_last_error.c_str(); }
 
-bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out) {
-    return guard([&] { REQUIRE(out); *out = nullptr; Engine *e = new Engine(device); *out = new bpg_ctx{e}; });
+static EngineConfig engine_config(const bpg_config *c) {
+    EngineConfig e;
+    if (!c) return e;
+    // struct_size tells which fields the caller's header knows; the layout only ever grows at the end
+    if (c->struct_size < offsetof(bpg_config, table_budget_gb)) throw std::invalid_argument("bpg_config.struct_size not set");
+    const size_t sz = c->struct_size;
+    e.profile = c->profile;
+    if (sz >= offsetof(bpg_config, chain_workers)) e.table_budget_gb = c->table_budget_gb;
+    if (sz >= offsetof(bpg_config, chain_lanes)) e.chain_workers = c->chain_workers;
+    if (sz >= offsetof(bpg_config, blocking_sync)) e.chain_lanes = c->chain_lanes;
+    if (sz >= offsetof(bpg_config, gens_cache_dir)) e.blocking_sync = c->blocking_sync;
+    if (sz >= sizeof(bpg_config) && c->gens_cache_dir) e.gens_cache_dir = c->gens_cache_dir;
+    return e;
 }
+bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config, bpg_ctx **out) {
+    return guard([&] { REQUIRE(out); *out = nullptr; Engine *e = new Engine(device, engine_config(config)); *out = new bpg_ctx{e}; });
+}
+bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out) { return bpg_ctx_create_ex(device, nullptr, out); }
+bpg_status bpg_test_fail_next_upload(bpg_ctx *ctx) { return guard([&] { REQUIRE(ctx); ctx->engine->test_fail_next_upload(); }); }
+uint64_t bpg_table_bytes(bpg_ctx *ctx) { return ctx ? ctx->engine->table_bytes() : 0; }
 void bpg_ctx_destroy(bpg_ctx *ctx) { if (ctx) { delete ctx->engine; delete ctx; } }
 bpg_status bpg_pedersen_bases(bpg_ctx *ctx, uint8_t B[32], uint8_t Bb[32]) { return guard([&] { REQUIRE(ctx && B && Bb); ctx->engine->pedersen_bases(B, Bb); }); }
 bpg_status bpg_gens_ensure(bpg_ctx *ctx, uint64_t capacity) { return guard([&] { REQUIRE(ctx); ctx->engine->gens_ensure(capacity); }); }
@@ -252,14 +269,15 @@ bpg_status bpg_r1cs_verify_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t ts[BPG
 
 // ---------------------------------------------------------------------------------------- batch pool
 struct bpg_pool { std::vector<bpg_ctx *> ctxs; };
-bpg_status bpg_pool_create(int32_t device, uint32_t workers, uint64_t gens_capacity, bpg_pool **out) {
+bpg_status bpg_pool_create(int32_t device, uint32_t workers, uint64_t gens_capacity, bpg_pool **out) { return bpg_pool_create_ex(device, workers, gens_capacity, nullptr, out); }
+bpg_status bpg_pool_create_ex(int32_t device, uint32_t workers, uint64_t gens_capacity, const bpg_config *config, bpg_pool **out) {
     if (!out) return BPG_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     if (workers < 1 || workers > 64) { g_last_error = "pool: 1..64 workers"; return BPG_ERR_INVALID_ARGUMENT; }
     bpg_pool *pool = new bpg_pool();
     for (uint32_t k = 0; k < workers; k++) {
         bpg_ctx *c = nullptr;
-        bpg_status s = bpg_ctx_create(device, &c);
+        bpg_status s = bpg_ctx_create_ex(device, config, &c);
         if (s == BPG_OK && gens_capacity) s = bpg_gens_ensure(c, gens_capacity);
         if (s != BPG_OK) { std::string keep = g_last_error; if (c) bpg_ctx_destroy(c); bpg_pool_destroy(pool); g_last_error = keep; return s; }
         pool->ctxs.push_back(c);

@@ -536,10 +536,7 @@ int main(int argc, char **argv) {
     else if (argc == 2 && self.find("verifier") != std::string::npos) { mode = "verifier"; name = argv[1]; }
     else if (argc == 2 && self.find("prover") != std::string::npos) { mode = "prover"; name = argv[1]; }
     else { std::fprintf(stderr, "usage: bpg_prover NAME | bpg_verifier NAME | %s prover|verifier NAME\n", self.c_str()); return 2; }
-    // a one-shot run makes ONE proof: the small fold tables (15 odd multiples, 7 ms to build at 2^20) instead of the serving profile
-    // (4 x 64 tables, 0.12 s to build, 1.7 ms less per proof); an explicit setting in the environment wins
-    setenv("BPG_FOLD_WNAF", "6", 0); setenv("BPG_FOLD_PARTS", "1", 0);
-    setenv("BPG_TT_WIDE_GB", "0", 0);          // likewise no 8-bit tail tables (17 GB at 2^14 for 0.6 ms per proof)
+    // a run makes ONE proof per stem: bpg_ctx_create's default, the one-shot profile (15 odd multiples, 7 ms to build at 2^20; no 8-bit tail tables)
     try {
         if (mode == "prover") { ProverRun r; r.name = name; return r.run(); }
         VerifierRun r; r.name = name; return r.run();

@@ -58,13 +58,27 @@ struct PinBuf {
 // first use, the odd multiples for the width-w NAF fold (one set per w).  Immutable once published, so contexts on different streams read them
 // freely; two proving streams then gather from ONE 201 MB table that the Infinity Cache holds, instead of two that evict each other.  A context that
 // needs a larger capacity moves to another generation; a generation is freed with its last context.
+// Bytes of precomputed multiples (fold tables + wide tail tables) held on each device by ALL generations of this process: what the table budget
+// of a context (bpg_config.table_budget_gb) is compared with, so that a process serving mixed circuit sizes cannot pin more than it was given.
+static std::mutex g_table_bytes_mutex;
+static std::map<int, uint64_t> g_table_bytes;
+static uint64_t table_bytes_held(int device) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); return g_table_bytes[device]; }
+static void table_bytes_add(int device, int64_t delta) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); g_table_bytes[device] = (uint64_t)((int64_t)g_table_bytes[device] + delta); }
 struct SharedTables {
     int device = 0; uint64_t cap = 0;
     DevBuf gens;
-    std::mutex m;                                   // guards odd (construction on first use)
+    std::mutex m;                                   // guards odd, wide, refused (construction on first use)
     std::map<uint32_t, DevBuf> wide;                // M0 -> 8-bit window tables of G[0..M0), H[0..M0) for a tail that starts on the original generators (k_tt_round8)
     std::map<uint32_t, DevBuf> odd;                 // (w | parts << 8) -> [parts * 2^(w-2) - 1][2*cap] Niels points: (2m+1) * 2^(j*L) * P, see FoldWnaf
-    ~SharedTables() { (void)hipSetDevice(device); gens.release(); for (auto &kv : odd) kv.second.release(); for (auto &kv : wide) kv.second.release(); }
+    std::map<uint64_t, uint64_t> refused;           // table key (odd: w | parts << 8; wide: 1 << 32 | M0) -> bytes held on the device when its allocation failed:
+                                                    // not tried again until the device holds less (no failing 50 GB hipMalloc per proof)
+    ~SharedTables() {
+        (void)hipSetDevice(device); gens.release();
+        uint64_t held = 0;
+        for (auto &kv : odd) { held += kv.second.cap; kv.second.release(); }
+        for (auto &kv : wide) { held += kv.second.cap; kv.second.release(); }
+        table_bytes_add(device, -(int64_t)held);
+    }
 };
 static std::mutex g_tables_mutex;                   // held across a derivation: contexts created side by side derive once
 static std::map<std::pair<int, uint64_t>, std::weak_ptr<SharedTables>> g_tables;
@@ -143,10 +157,9 @@ uint64_t gens_checksum(const uint8_t *p, size_t n) {            // four interlea
     for (; i < n; i++) h[0] = (h[0] ^ p[i]) * 0x100000001b3ull;
     return h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (uint64_t)n;
 }
-std::string gens_cache_path(uint64_t cap) {
-    const char *dir = std::getenv("BPG_GENS_CACHE_DIR");
-    if (!dir || !*dir) return std::string();
-    return std::string(dir) + "/gens_" + std::to_string(cap) + ".bpg";
+std::string gens_cache_path(const std::string &dir, uint64_t cap) {
+    if (dir.empty()) return std::string();
+    return dir + "/gens_" + std::to_string(cap) + ".bpg";
 }
 
 }  // namespace
@@ -227,50 +240,64 @@ struct Engine::Impl {
         if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
     }
     // 8-bit window tables of the original generators (kernels.cuh k_tt_round8): shared per device like the fold tables, built on first use
-    uint64_t tt_wide_budget = 24ull << 30;      // BPG_TT_WIDE_GB; 0 = never (17.2 GB at M0 = 2^14)
+    // Budgets.  table_budget bounds the CUMULATIVE bytes of precomputed multiples (fold tables + wide tail tables, every capacity) this process
+    // holds on the device (bpg_config.table_budget_gb / BPG_TABLE_GB; profile default: one-shot 4 GB, serving 96 GB); the two per-kind caps are
+    // diagnostics (BPG_TT_WIDE_GB, BPG_FOLD_TABLE_GB).
+    uint64_t table_budget = 4ull << 30;
+    uint64_t tt_wide_budget = 0;                // widest single 8-bit tail table (17.2 GB at M0 = 2^14); 0 = never (the one-shot profile)
+    std::string gens_cache_dir;                 // bpg_config.gens_cache_dir / BPG_GENS_CACHE_DIR
+    bool table_fits(uint64_t key, uint64_t bytes) const {          // shared->m held
+        const uint64_t held = table_bytes_held(shared->device);
+        auto it = shared->refused.find(key);
+        if (it != shared->refused.end() && held >= it->second) return false;      // failed with this much (or less) held: do not try again
+        return held + bytes <= table_budget;
+    }
     const ge_pniels *wide_ensure(uint32_t M0) {
         const uint64_t bytes = (uint64_t)2 * M0 * TT8_WINDOWS * TT8_MULTS * sizeof(ge_pniels);
         if (M0 < 64 || bytes > tt_wide_budget) return nullptr;
         std::lock_guard<std::mutex> lk(shared->m);
         auto it = shared->wide.find(M0);
         if (it != shared->wide.end()) return it->second.as<ge_pniels>();
+        const uint64_t key = (1ull << 32) | M0;
+        if (!table_fits(key, bytes)) return nullptr;                             // the 4-bit tables of the context do
         DevBuf table, bases8;
         try { table.ensure(bytes); bases8.ensure((size_t)2 * M0 * TT8_WINDOWS * sizeof(ge_ext)); }
-        catch (const std::exception &) { (void)hipGetLastError(); table.release(); bases8.release(); return nullptr; }      // no room: the 4-bit tables do
+        catch (const std::exception &) { (void)hipGetLastError(); table.release(); bases8.release(); shared->refused[key] = table_bytes_held(shared->device); return nullptr; }
         BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
         BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         bases8.release();
         shared->wide[M0] = table;
+        table_bytes_add(shared->device, (int64_t)table.cap);
         return table.as<ge_pniels>();
     }
     PinBuf h_naf;
     // odd multiples (2m+1) * 2^(j*L) * P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf, scalars
     // cut into `fold_parts` pieces of L bits); built on first use for the device's generator tables and shared with them
     DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
-    uint32_t fold_wnaf = 8;
-    uint32_t fold_parts = 4;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2 or 4)
-    uint64_t fold_table_budget = 64ull << 30;       // bytes of HBM the fold tables of one device may take (BPG_FOLD_TABLE_GB): larger capacities get fewer parts, then narrower windows
+    uint32_t fold_wnaf = 6;          // width of the NAF the first fold recodes its scalars in (BPG_FOLD_WNAF; one-shot profile 6, serving 8; 0 = register kernels)
+    uint32_t fold_parts = 1;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2 or 4; serving 4)
+    uint64_t fold_table_budget = 64ull << 30;       // per-kind cap of the fold tables (BPG_FOLD_TABLE_GB); the cumulative bound is table_budget
     uint32_t eff_wnaf = 0, eff_parts = 0;            // what odd_ensure settled on for the current capacity
     uint32_t fold_part_bits() const { return (254 + eff_parts - 1) / eff_parts; }
-    void odd_ensure() {
+    // false: no table of any width fits the budget (or the device): the caller folds with the register kernels
+    bool odd_ensure() {
         eff_wnaf = fold_wnaf; eff_parts = fold_parts;
         auto table_bytes = [&](uint32_t w, uint32_t parts) { return ((uint64_t)parts * (1u << (w - 2)) - 1) * 2 * gens_cap * sizeof(ge_niels); };
-        while (table_bytes(eff_wnaf, eff_parts) > fold_table_budget && (eff_parts > 1 || eff_wnaf > 3)) { if (eff_parts > 1) eff_parts /= 2; else eff_wnaf--; }
+        auto smaller = [&]() { if (eff_parts > 1) { eff_parts /= 2; return true; } if (eff_wnaf > 3) { eff_wnaf--; return true; } return false; };
         std::lock_guard<std::mutex> lk(shared->m);
-        const uint32_t key = eff_wnaf | (eff_parts << 8);
-        auto it = shared->odd.find(key);
-        if (it != shared->odd.end()) { gens_odd = it->second; return; }
         DevBuf odd;
-        for (;;) {   // a device that cannot spare the tables of this profile (other tenants) gets the next smaller one
-            try { odd.ensure(table_bytes(eff_wnaf, eff_parts)); break; }
-            catch (const std::exception &) {
-                (void)hipGetLastError();
-                if (eff_parts > 1) eff_parts /= 2; else if (eff_wnaf > 3) eff_wnaf--; else throw;
-                auto it2 = shared->odd.find(eff_wnaf | (eff_parts << 8));
-                if (it2 != shared->odd.end()) { gens_odd = it2->second; return; }
+        for (;;) {   // the widest profile that is already built, or fits the budgets and the device (other tenants): the next smaller one otherwise
+            const uint32_t key = eff_wnaf | (eff_parts << 8);
+            auto it = shared->odd.find(key);
+            if (it != shared->odd.end()) { gens_odd = it->second; return true; }
+            const uint64_t bytes = table_bytes(eff_wnaf, eff_parts);
+            if (bytes <= fold_table_budget && table_fits(key, bytes)) {
+                try { odd.ensure(bytes); break; }
+                catch (const std::exception &) { (void)hipGetLastError(); odd.release(); shared->refused[key] = table_bytes_held(shared->device); }
             }
+            if (!smaller()) { gens_odd = DevBuf(); return false; }
         }
         const uint32_t key_built = eff_wnaf | (eff_parts << 8);
         const uint32_t NM = 1u << (eff_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
@@ -295,7 +322,9 @@ struct Engine::Impl {
         HIPCHK(hipStreamSynchronize(st));
         dbl.release(); base.release();
         shared->odd[key_built] = odd;
+        table_bytes_add(shared->device, (int64_t)odd.cap);
         gens_odd = odd;
+        return true;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
@@ -321,6 +350,11 @@ struct Engine::Impl {
         static constexpr uint64_t UP = 65536;
         int device = 0; hipStream_t copy_st = nullptr; uint8_t *d_raw = nullptr; std::vector<hipEvent_t> *ev = nullptr;
         std::atomic<uint64_t> uploaded_blocks{0};
+        // first HIP error of this stream's uploads (hipError_t, 0 = none), stored BEFORE uploaded_blocks is published: the device slab is reused
+        // from proof to proof, so a block that was not copied would hand prove() the previous proof's draws - prove() checks and refuses
+        std::atomic<int> err{0};
+        bool inject_fail = false;                                   // bpg_test_fail_next_upload
+        void note(hipError_t e) { if (e != hipSuccess) { int want = 0; err.compare_exchange_strong(want, (int)e, std::memory_order_release); } }
     };
     struct ChainWorker {                                     // the context's chain threads: one by default, `workers` draw queued streams side by side
         std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
@@ -336,8 +370,10 @@ struct Engine::Impl {
                 if (to <= L.up) return;
                 BlindStream &b = *L.b;
                 const uint64_t k = L.up / BlindStream::UP;
-                (void)hipMemcpyAsync(b.d_raw + 64 * L.up, b.raw + 64 * L.up, (to - L.up) * 64, hipMemcpyHostToDevice, b.copy_st);
-                (void)hipEventRecord((*b.ev)[k], b.copy_st);
+                b.note(hipSetDevice(b.device));                                         // lanes of one thread may belong to contexts of different devices
+                b.note(hipMemcpyAsync(b.d_raw + 64 * L.up, b.raw + 64 * L.up, (to - L.up) * 64, hipMemcpyHostToDevice, b.copy_st));
+                b.note(hipEventRecord((*b.ev)[k], b.copy_st));
+                if (b.inject_fail) b.note(hipErrorUnknown);
                 L.up = to;
                 b.uploaded_blocks.store(k + 1, std::memory_order_release);
             };
@@ -348,7 +384,6 @@ struct Engine::Impl {
                     while (act.size() < w->lanes && !w->pending.empty()) {
                         std::shared_ptr<BlindStream> b = w->pending.front(); w->pending.pop_front();
                         b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
-                        (void)hipSetDevice(b->device);
                         act.push_back(Lane{b, b->snaps[0], 0, 0});
                     }
                 }
@@ -375,14 +410,15 @@ struct Engine::Impl {
                 std::shared_ptr<BlindStream> b;
                 { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
                 b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
-                (void)hipSetDevice(b->device);
+                b->note(hipSetDevice(b->device));
                 TranscriptRng rng = b->snaps[0];
                 uint64_t pos = 0, up = 0;                                               // up: draws handed to the copy stream
                 auto upload = [&](uint64_t to) {                                        // block [up, to) -> device, then its event
                     if (to <= up) return;
                     const uint64_t k = up / BlindStream::UP;
-                    (void)hipMemcpyAsync(b->d_raw + 64 * up, b->raw + 64 * up, (to - up) * 64, hipMemcpyHostToDevice, b->copy_st);
-                    (void)hipEventRecord((*b->ev)[k], b->copy_st);
+                    b->note(hipMemcpyAsync(b->d_raw + 64 * up, b->raw + 64 * up, (to - up) * 64, hipMemcpyHostToDevice, b->copy_st));
+                    b->note(hipEventRecord((*b->ev)[k], b->copy_st));
+                    if (b->inject_fail) b->note(hipErrorUnknown);
                     up = to;
                     b->uploaded_blocks.store(k + 1, std::memory_order_release);
                 };
@@ -408,6 +444,7 @@ struct Engine::Impl {
     struct SlabDev { DevBuf d; hipStream_t copy_st = nullptr; std::vector<hipEvent_t> ev; };
     std::vector<std::unique_ptr<SlabDev>> slab_dev;         // device side of each slab: the uploaded draws, the copy stream, one event per block
     int last_chain_cpu = -1;
+    bool test_fail_upload = false;
     static void blind_stop(const std::shared_ptr<BlindStream> &b) {       // returns once the worker no longer touches b's slab
         b->stop.store(true, std::memory_order_relaxed);
     }
@@ -473,24 +510,45 @@ struct Engine::Impl {
                        const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0);
 };
 
-Engine::Engine(int device) : device_(device) {
+Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
+    if (cfg.profile > 2) throw std::invalid_argument("bpg_config.profile: 0 (default), 1 (one-shot) or 2 (serving)");
+    if (cfg.table_budget_gb < 0 || cfg.table_budget_gb > 4096) throw std::invalid_argument("bpg_config.table_budget_gb: 0 (default) .. 4096");
+    if (cfg.chain_workers > 64) throw std::invalid_argument("bpg_config.chain_workers: 0 (default), 1..64");
+    if (cfg.chain_lanes > 8) throw std::invalid_argument("bpg_config.chain_lanes: 0 (default), 1..8");
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available: the bpg engine has no CPU path");
     if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
     HIPCHK(hipSetDevice(device));
-    if (const char *e = std::getenv("BPG_SYNC_BLOCKING")) { if (std::atoi(e) != 0) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); } }
+    // What the host chose (bpg_config): the struct first, then the environment variable, then the profile's default.
+    auto env_int = [](const char *name, int lo, int hi, int &out) { if (const char *e = std::getenv(name)) { const int v = std::atoi(e); if (v >= lo && v <= hi) { out = v; return true; } } return false; };
+    int blocking = cfg.blocking_sync; if (blocking < 0) { blocking = 0; (void)env_int("BPG_SYNC_BLOCKING", 0, 1, blocking); }
+    if (blocking) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
     impl_ = new Impl();
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
+    uint32_t profile = cfg.profile;
+    if (profile == 0) { if (const char *e = std::getenv("BPG_PROFILE")) profile = (!std::strcmp(e, "serving") || !std::strcmp(e, "2")) ? 2u : 1u; else profile = 1u; }
+    // one-shot (the default of a bare bpg_ctx_create): width-6 NAF fold tables on whole scalars (3.0 GB at 2^20, built in 7 ms), no 8-bit tail
+    // tables, 4 GB of tables in all; serving: width-8 NAF on scalars cut in four (51.5 GB at 2^20, 0.12 s), 8-bit tail tables (17.2 GB at 2^14), 96 GB
+    if (profile == 2) { impl_->fold_wnaf = 8; impl_->fold_parts = 4; impl_->tt_wide_budget = 24ull << 30; impl_->table_budget = 96ull << 30; }
+    else { impl_->fold_wnaf = 6; impl_->fold_parts = 1; impl_->tt_wide_budget = 0; impl_->table_budget = 4ull << 30; }
+    {
+        double gb = cfg.table_budget_gb;
+        if (!(gb > 0)) { if (const char *e = std::getenv("BPG_TABLE_GB")) gb = std::atof(e); }
+        if (gb > 0 && gb <= 4096) impl_->table_budget = (uint64_t)(gb * (double)(1ull << 30));
+    }
+    { int v = (int)cfg.chain_workers; if (v == 0) (void)env_int("BPG_CHAIN_WORKERS", 1, 64, v); if (v != 0) impl_->chain_workers = (uint32_t)v; }
+    { int v = (int)cfg.chain_lanes; if (v == 0) (void)env_int("BPG_CHAIN_LANES", 1, 8, v); if (v != 0) impl_->chain_lanes = (uint32_t)v; }
+    impl_->gens_cache_dir = cfg.gens_cache_dir;
+    if (impl_->gens_cache_dir.empty()) { if (const char *e = std::getenv("BPG_GENS_CACHE_DIR")) impl_->gens_cache_dir = e; }
+    // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_MSM_SORT")) { int v = std::atoi(e); if (v == 1 || v == 2) impl_->sort_levels = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_SHIFT")) { int v = std::atoi(e); if (v >= 0 && v <= 10) impl_->tile_shift = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("BPG_CHAIN_LANES")) { int v = std::atoi(e); if (v >= 1 && v <= 8) impl_->chain_lanes = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_CHAIN_WORKERS")) { int v = std::atoi(e); if (v >= 1 && v <= 64) impl_->chain_workers = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
@@ -616,7 +674,7 @@ void Engine::gens_ensure(uint64_t capacity) {
         if (share) g_tables[{device_, cap}] = sp;
         I.adopt(sp); gens_cap_ = cap;
     };
-    const std::string cache_file = gens_cache_path(cap);
+    const std::string cache_file = gens_cache_path(I.gens_cache_dir, cap);
     if (!cache_file.empty()) { DevBuf loaded; if (I.gens_load_cached(cache_file, cap, loaded)) { publish(loaded); return; } }
     I.h_raw.ensure(2 * cap * 64);
     {   // the two chains are independent XOF streams: squeeze them on two threads; the streams are prefixes of one another across
@@ -1119,10 +1177,11 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
             }
             ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
-            const bool use_wnaf = I.fold_wnaf >= 3 && !I.fold_from_memory && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max;
+            // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf) -
+            // unless no table fits the budget of this device, in which case the register kernels below fold them
+            const bool use_wnaf = I.fold_wnaf >= 3 && !I.fold_from_memory && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max
+                                  && I.odd_ensure();
             if (use_wnaf) {
-                // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf)
-                I.odd_ensure();
                 const uint32_t parts = I.eff_parts, L = I.fold_part_bits(), nq = nterms * parts;
                 const size_t dbytes = (size_t)4 * nq * 256;
                 I.h_naf.ensure(dbytes); I.naf.ensure(dbytes);
@@ -1235,6 +1294,7 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     TranscriptRng rng = T.build_rng(v_blinding, seed);
     for (int k = 0; k < 3; k++) b->first[k] = rng.random_scalar();
     b->max_draws = ((2 * max_multipliers + BS::SNAP - 1) / BS::SNAP) * BS::SNAP;
+    b->inject_fail = I.test_fail_upload; I.test_fail_upload = false;
     // pinned slab: one that no alive stream owns; its previous owner must have left it (its uploads were synchronised by the prove() that used it)
     if (I.h_blind.size() < max_alive) { I.h_blind.resize(max_alive); I.slab_owner.resize(max_alive); while (I.slab_dev.size() < max_alive) I.slab_dev.emplace_back(std::make_unique<Impl::SlabDev>()); }
     int slot = -1;
@@ -1273,6 +1333,8 @@ void Engine::set_chain_lanes(uint32_t n) {
     impl_->chain_lanes = n;
 }
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
+void Engine::test_fail_next_upload() { impl_->test_fail_upload = true; }
+uint64_t Engine::table_bytes() const { return table_bytes_held(device_); }
 int Engine::chain_cpu() const { return impl_->last_chain_cpu; }
 
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
@@ -1381,6 +1443,12 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
                 // stream, then make this stream wait for its event - no host copy, no copy on this stream
                 const uint64_t k = i / Impl::BlindStream::UP;
                 while (bs->uploaded_blocks.load(std::memory_order_acquire) <= k) std::this_thread::sleep_for(std::chrono::microseconds(40));
+                if (const int uerr = bs->err.load(std::memory_order_acquire)) {
+                    // the slab on the device may still hold an earlier proof's draws: s_L, s_R must never be built from it
+                    Impl::blind_stop(bs);
+                    for (auto it = I.blinds.begin(); it != I.blinds.end(); ++it) if (it->get() == bs.get()) { I.blinds.erase(it); break; }
+                    throw DeviceError(std::string("upload of the blinding draws failed: ") + hipGetErrorString((hipError_t)uerr));
+                }
                 HIPCHK(hipStreamWaitEvent(st, (*bs->ev)[k], 0));
                 BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt);
             } else {

@@ -19,9 +19,20 @@ struct ProveTimings {       // milliseconds, host wall clock around each phase (
 
 struct DeviceCircuit;       // HBM-resident flattened R1CS instance
 
+// What a host chooses at context creation (include/bpg.h bpg_config).  A field left at its "unset" value falls back to the environment
+// variable named beside it, then to the profile's default.
+struct EngineConfig {
+    uint32_t profile = 0;           // 0 unset (BPG_PROFILE, else one-shot), 1 one-shot, 2 serving
+    double table_budget_gb = 0;     // cumulative HBM the precomputed generator multiples of this device may take (BPG_TABLE_GB); 0 unset
+    uint32_t chain_workers = 0;     // 0 unset (BPG_CHAIN_WORKERS, else 1)
+    uint32_t chain_lanes = 0;       // 0 unset (BPG_CHAIN_LANES, else 1)
+    int32_t blocking_sync = -1;     // -1 unset (BPG_SYNC_BLOCKING, else 0)
+    std::string gens_cache_dir;     // empty unset (BPG_GENS_CACHE_DIR, else no cache)
+};
+
 class Engine {
 public:
-    explicit Engine(int device);
+    explicit Engine(int device, const EngineConfig &cfg = EngineConfig());
     ~Engine();
     Engine(const Engine &) = delete;
     Engine &operator=(const Engine &) = delete;
@@ -50,6 +61,8 @@ public:
     // threads of the context's chain worker: that many queued streams are drawn side by side, workers + 1 may be alive (default 1)
     void set_chain_workers(uint32_t n);
     void set_chain_lanes(uint32_t n);        // streams each chain thread draws in lockstep (1..8; eight sponges in the lanes of ZMM registers)
+    void test_fail_next_upload();   // test hook (bpg_test_fail_next_upload)
+    uint64_t table_bytes() const;   // precomputed generator multiples held on this device by the process
     int chain_cpu() const;      // host core the chain worker last drew a stream on (-1: none yet); diagnostics for bench.py
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
     // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.

@@ -15,22 +15,28 @@ def blinding(cfg: str, index: int) -> bytes:
     return (int.from_bytes(synth(cfg + "-blind", index, 64), "little") % L).to_bytes(32, "little")
 
 
+def _setup(g, p, scalars, blindings):
+    """Gadget::setup (reference src/gadget.rs:18-38); a prover that makes its commitments outside the library (the fixture generator of
+    tests/golden, which has no device) brings its own."""
+    return p.gadget_setup(g, scalars, blindings) if hasattr(p, "gadget_setup") else g.setup(p, scalars, blindings)
+
+
 class Assembled:
     """A prover with every gadget assembled, plus what a verifier needs to rebuild the same statement."""
     def __init__(self, prover, transcript, commitments, gens_capacity, replay):
         self.prover, self.transcript, self.commitments, self.gens_capacity, self.replay = prover, transcript, commitments, gens_capacity, replay
 
 
-def bounds_check_64(ctx, seed=0, label=b"BoundsCheck"):
+def bounds_check_64(ctx, seed=0, label=b"BoundsCheck", prover_cls=Prover):
     """cfg 2: one BOUND W0 I0 I1 with 8-byte bounds (64-bit range proofs): n = N = 128, q = 259, m = 3."""
     cfg = "cfg2-%d" % seed
     lo, hi = bytes(8), b"\xff" * 8
     witness = synth(cfg, 0, 8)
     t = Transcript(label)
-    p = Prover(ctx, t)
+    p = prover_cls(ctx, t)
     g = BoundsCheck(lo, hi)
     scalars, wcoms, wvars = commit(p, witness, [blinding(cfg, 0)])
-    dcoms, derived = g.setup(p, scalars, [blinding(cfg, 1), blinding(cfg, 2)])
+    dcoms, derived = _setup(g, p, scalars, [blinding(cfg, 1), blinding(cfg, 2)])
     g.prove(p, wvars, derived)
 
     def replay(v):
@@ -41,17 +47,17 @@ def bounds_check_64(ctx, seed=0, label=b"BoundsCheck"):
     return Assembled(p, t, wcoms + dcoms, 128, replay)
 
 
-def mimc_preimage(ctx, nbytes=2130, seed=0, label=b"MiMCHash"):
+def mimc_preimage(ctx, nbytes=2130, seed=0, label=b"MiMCHash", prover_cls=Prover):
     """cfg 3: one HASH I0 W0 over a seeded preimage; 2130 bytes -> 67 absorbed blocks, n = 65,124, N = 2^16."""
     cfg = "cfg3-%d" % seed
     pre = synth(cfg, 0, nbytes)
     image = mimc_hash(pre)
     t = Transcript(label)
-    p = Prover(ctx, t)
+    p = prover_cls(ctx, t)
     g = MimcHash256(image)
     nblocks = (nbytes + 31) // 32
     scalars, wcoms, wvars = commit(p, pre, [blinding(cfg, i) for i in range(nblocks)])
-    dcoms, derived = g.setup(p, scalars, [blinding(cfg, 1000), blinding(cfg, 1001)])
+    dcoms, derived = _setup(g, p, scalars, [blinding(cfg, 1000), blinding(cfg, 1001)])
     g.prove(p, wvars, derived)
     n = p.get_num_multiplications()
     cap = 1
@@ -75,7 +81,7 @@ def full_tree_pattern(leaves: int) -> str:
     return pat
 
 
-def merkle_full_tree(ctx, leaves=512, seed=None, label=b"MerkleTree"):
+def merkle_full_tree(ctx, leaves=512, seed=None, label=b"MerkleTree", prover_cls=Prover):
     """cfg 4: MerkleTree256 over a full binary tree with every leaf a committed witness
     (reference src/merkle_tree/merkle_tree_gadget.rs:473-545: 512 leaves, n = 993,384, N = 2^20, m = 512).
     seed None reproduces the reference's instance (512 x leaf W1, root at :476); an integer derives distinct leaves."""
@@ -85,7 +91,7 @@ def merkle_full_tree(ctx, leaves=512, seed=None, label=b"MerkleTree"):
     else:
         leaf_be = [b"\x07" + synth(cfg, i, 31) for i in range(leaves)]      # top byte small: canonical scalars
     t = Transcript(label)
-    p = Prover(ctx, t)
+    p = prover_cls(ctx, t)
     scalars, wcoms, wvars = commit_all_single(p, leaf_be, [blinding(cfg, i) for i in range(leaves)])
     pattern = full_tree_pattern(leaves)
     if seed is None and leaves == 512:

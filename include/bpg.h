@@ -10,6 +10,13 @@
  * output; every function returns a bpg_status (0 = ok) and never unwinds across the boundary; a context (and the
  * objects created from it) is used by one host thread at a time, different contexts are independent.
  * There is NO CPU fallback: bpg_ctx_create fails with BPG_ERR_DEVICE when no AMD GPU is visible.
+ *
+ * SIDE CHANNELS - read before proving with secrets on shared hardware.  Upstream computes A_I, A_O, S, T_k and every Pedersen commitment with
+ * a CONSTANT-TIME multiscalar multiplication (Straus, fixed table lookups) because their scalars are secret: the witness a_L, a_R, a_O, the
+ * blinding vectors s_L, s_R and the blinding factors.  This library does not: those scalars go through the bucket method (digit-indexed
+ * scatter and gather) and, in the table-driven paths, through digit-indexed table reads with zero digits skipped; the host's Horner
+ * recombination and the scalar arithmetic of host/scalar.hpp are variable-time as well.  Memory access pattern and running time therefore depend
+ * on secret data.  The proof bytes are the same; the posture is that of a prover on a machine its operator trusts.
  */
 #ifndef BPG_H
 #define BPG_H
@@ -70,8 +77,29 @@ typedef struct {                  /* milliseconds; filled when a non-NULL pointe
 const char *bpg_strerror(bpg_status s);
 const char *bpg_last_error(void);                                /* message of the calling thread's last failure */
 
-/* replaces PedersenGens::default() + device selection            (reference src/bin/prover.rs:53) */
+/* replaces PedersenGens::default() + device selection            (reference src/bin/prover.rs:53).
+ * bpg_ctx_create(device, out) = bpg_ctx_create_ex(device, NULL, out): the ONE-SHOT profile - what a process that proves once and exits wants
+ * (the reference's prover binary, src/bin/prover.rs:47-100): at most 4 GB of precomputed tables beside the generators (3.0 GB at 2^20, 7 ms).
+ * bpg_ctx_create_ex takes the choices a host has: a zeroed bpg_config with struct_size set means "defaults"; a field left at 0 / -1 / NULL falls
+ * back to the environment variable named beside it, then to the profile's default.  Every setting gives the same proof bytes. */
+#define BPG_PROFILE_DEFAULT 0u   /* BPG_PROFILE=oneshot|serving if set, else one-shot */
+#define BPG_PROFILE_ONESHOT 1u   /* first generator fold on width-6 NAF tables of whole scalars; no 8-bit tail tables; table budget 4 GB */
+#define BPG_PROFILE_SERVING 2u   /* a long-lived prover: width-8 NAF on scalars cut in four (51.5 GB of tables at 2^20, built once per device in 0.12 s,
+                                    shared by the contexts of the process: -2.4 ms per 2^20 proof), 8-bit tail tables for circuits up to 2^14
+                                    multipliers (17.2 GB); table budget 96 GB */
+typedef struct {
+    uint32_t struct_size;        /* size of this struct in bytes as the caller compiled it: lets the struct grow */
+    uint32_t profile;            /* BPG_PROFILE_* */
+    double table_budget_gb;      /* cumulative HBM all precomputed generator multiples of this process on the device may take (BPG_TABLE_GB); what does
+                                    not fit is replaced by the next smaller table set, in the end by kernels that need none; 0 = profile default */
+    uint32_t chain_workers;      /* bpg_ctx_set_chain_workers at creation (BPG_CHAIN_WORKERS); 0 = default 1 */
+    uint32_t chain_lanes;        /* bpg_ctx_set_chain_lanes at creation (BPG_CHAIN_LANES); 0 = default 1 */
+    int32_t blocking_sync;       /* 1: host threads sleep in stream waits (hipDeviceScheduleBlockingSync; device-wide, first context of the process
+                                    decides) - for hosts that run many proving threads beside their chain threads; 0 spin; -1 = BPG_SYNC_BLOCKING, else 0 */
+    const char *gens_cache_dir;  /* directory of the on-disk generator cache (BPG_GENS_CACHE_DIR); NULL = no cache */
+} bpg_config;
 bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out);
+bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config /* NULL = defaults */, bpg_ctx **out);
 void bpg_ctx_destroy(bpg_ctx *ctx);
 bpg_status bpg_pedersen_bases(bpg_ctx *ctx, uint8_t B[32], uint8_t B_blinding[32]);
 
@@ -124,6 +152,7 @@ typedef struct {
     uint8_t *proof_out; uint64_t *proof_len;   /* in = capacity, out = bytes written */
 } bpg_batch_item;
 bpg_status bpg_pool_create(int32_t device, uint32_t workers, uint64_t gens_capacity, bpg_pool **out);
+bpg_status bpg_pool_create_ex(int32_t device, uint32_t workers, uint64_t gens_capacity, const bpg_config *config /* of every context; NULL = defaults */, bpg_pool **out);
 void bpg_pool_destroy(bpg_pool *pool);
 bpg_status bpg_pool_prove(bpg_pool *pool, uint64_t count, const bpg_batch_item *items, bpg_status *status_out);
 
@@ -135,6 +164,11 @@ bpg_status bpg_bench_fe_mul(bpg_ctx *ctx, uint32_t iters, double *mults_per_seco
 
 /* test hook: device field arithmetic on n pairs of raw 256-bit values; op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 mixed chain; canonical output */
 bpg_status bpg_test_fe_ops(bpg_ctx *ctx, int32_t op, uint64_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
+/* test hook: the next blinding stream started on ctx (bpg_blinding_begin) records a failed upload of its first block, as a failing hipMemcpyAsync
+ * would: the prove that adopts it must fail with BPG_ERR_DEVICE instead of reading a stale device slab */
+bpg_status bpg_test_fail_next_upload(bpg_ctx *ctx);
+/* diagnostics: bytes of precomputed generator multiples (fold tables + wide tail tables) this process holds on the context's device */
+uint64_t bpg_table_bytes(bpg_ctx *ctx);
 /* test hook: compress(sum s_i*G[first+i] + t_i*H[first+i]) through the bucket-method MSM kernels */
 bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
 

@@ -461,35 +461,8 @@ def test_fold_group_sizes_above_the_tail(ctx, blocks, N):
     res.free()
 
 
-def test_fold_profiles_agree_at_half_a_million_multipliers(monkeypatch):
-    """At N = 2^19 the DEFAULT schedule takes the width-w NAF fold (the small cases force it with BPG_FOLD_SPLIT=0): the serving profile (width 8,
-    scalars cut in four), the one-shot profile of the file drivers (width 6, unsplit), a two-part split and the register kernels (no tables) must
-    give the same proof, which the GPU verifier accepts and rejects when tampered.  (bench.py compares the serving profile with the oracle
-    prover at 2^20 in every default run.)"""
-    proofs = {}
-    for name, env in (("serving", {}), ("one-shot", {"BPG_FOLD_WNAF": "6", "BPG_FOLD_PARTS": "1"}), ("two parts", {"BPG_FOLD_WNAF": "7", "BPG_FOLD_PARTS": "2"}),
-                      ("registers", {"BPG_FOLD_WNAF": "0"})):
-        for k in ("BPG_FOLD_WNAF", "BPG_FOLD_PARTS"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        c = bpg.Context(0)
-        try:
-            a = workloads.merkle_full_tree(c, leaves=256, seed=5)
-            inst = a.prover.instance()
-            assert a.gens_capacity == 1 << 19
-            c.gens_ensure(a.gens_capacity)
-            res = c.upload(inst)
-            proofs[name] = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)[0]
-            if name == "serving":
-                coms = b"".join(a.commitments)
-                assert res.verify(a.transcript.state, coms, proofs[name]) == 0
-                bad = bytearray(proofs[name]); bad[len(bad) // 2] ^= 1
-                assert res.verify(a.transcript.state, coms, bytes(bad)) != 0
-            res.free()
-        finally:
-            c.close()
-    assert len(set(proofs.values())) == 1, {k: v[:8].hex() for k, v in proofs.items()}
+# (the fold profiles at N = 2^19 and 2^20 - serving, one-shot, two-part split, register kernels - are compared with oracle-generated fixtures in
+# tests/test_proof_fixtures.py::test_gpu_reproduces_full_size_fixtures)
 
 
 def test_expanded_blinding_dialect_matches_oracle_and_verifies(ctx):
@@ -797,7 +770,7 @@ def test_tail_on_original_generators_with_and_without_wide_tables(wide_gb, monke
     also for the second proof on the same context (cached tables) and for a circuit of another size on the same context."""
     monkeypatch.setenv("BPG_TT_WIDE_GB", wide_gb)
     monkeypatch.setenv("BPG_GENS_SHARE", "0")
-    c = bpg.Context(0)
+    c = bpg.Context(0, profile="serving")                   # the one-shot default never builds them (4.3 GB at N = 4096)
     try:
         cases = [workloads.mimc_preimage(c, nbytes=20, seed=3, label=b"MiMCHash"),      # n = 972, N = 1024
                  workloads.bounds_check_64(c, seed=1),                                  # n = N = 128
@@ -814,6 +787,87 @@ def test_tail_on_original_generators_with_and_without_wide_tables(wide_gb, monke
             res.free()
     finally:
         c.close()
+
+
+def test_profiles_and_the_cumulative_table_budget(ctx, monkeypatch):
+    """bpg_ctx_create = the one-shot profile (15 odd multiples per generator); bpg_ctx_create_ex chooses: serving = 255 multiples; a table budget counts
+    every table the process holds on the device (both capacities below together), and what does not fit is replaced by the next smaller set, in the
+    end by the register kernels.  Same bytes as the oracle every time."""
+    monkeypatch.setenv("BPG_TT_LG", "0")
+    monkeypatch.setenv("BPG_FOLD_SPLIT", "0")            # the width-w NAF fold at this small size
+    monkeypatch.setenv("BPG_GENS_SHARE", "0")
+    for k in ("BPG_PROFILE", "BPG_FOLD_WNAF", "BPG_FOLD_PARTS", "BPG_TABLE_GB", "BPG_FOLD_TABLE_GB"):
+        monkeypatch.delenv(k, raising=False)
+    row = lambda cap: 2 * cap * 96                          # one table of multiples: [G | H] in affine Niels form
+    def run(c, nbytes, seed):
+        a = workloads.mimc_preimage(c, nbytes=nbytes, seed=seed, label=b"MiMCHash")
+        inst = a.prover.instance()
+        c.gens_ensure(a.gens_capacity)
+        res = c.upload(inst)
+        proof, _ = res.prove(a.transcript.state, inst.v_blinding, bytes(range(32)), 0)
+        rc, want, _ = O.prove(O.Gens(a.gens_capacity), a.transcript.state, to_oracle(inst), inst.v_blinding, bytes(range(32)), O.FLAG_FAST_MSM)
+        assert rc == 0 and proof == want
+        res.free()
+        return a.gens_capacity
+    for kw, tables in (({}, 15), ({"profile": "oneshot"}, 15), ({"profile": "serving"}, 255)):
+        c = bpg.Context(0, **kw)
+        try:
+            before = c.table_bytes()
+            cap = run(c, 20, 3)                            # N = 1024
+            assert c.table_bytes() - before == tables * row(cap), (kw, c.table_bytes() - before)
+            run(c, 20, 3)                                   # second proof: nothing new
+            assert c.table_bytes() - before == tables * row(cap)
+        finally:
+            c.close()
+        assert ctx.table_bytes() == before                  # freed with the last context of the generation
+    # 5.5 MB on top of what the process already holds: the serving set of N = 1024 (255 x 196,608 B = 50 MB) shrinks - two parts, one part, width 7
+    # (31 tables, 6.1 MB) - to width 6 unsplit (15 tables, 2.9 MB); the next capacity on the same device (N = 2048: 15 tables = 5.9 MB, 7 = 2.8 MB)
+    # no longer fits beside it until width 4 (3 tables, 1.2 MB)
+    before = ctx.table_bytes()
+    c = bpg.Context(0, profile="serving", table_budget_gb=(before + 5.5e6) / 2**30)
+    try:
+        cap = run(c, 20, 3)
+        assert c.table_bytes() - before == 15 * row(cap)
+        c2 = bpg.Context(0, profile="serving", table_budget_gb=(before + 5.5e6) / 2**30)
+        try:
+            cap2 = run(c2, 50, 5)                          # N = 2048
+            assert c2.table_bytes() - before == 15 * row(cap) + 3 * row(cap2)
+        finally:
+            c2.close()
+    finally:
+        c.close()
+    # no budget at all: the register kernels fold, no table is built
+    c = bpg.Context(0, table_budget_gb=1e-6)
+    try:
+        run(c, 20, 3)
+        assert c.table_bytes() == before
+    finally:
+        c.close()
+    with pytest.raises(bpg.BpgError):
+        bpg.Context(0, profile=2, chain_lanes=9)
+
+
+def test_failed_upload_of_blinding_draws_is_refused(ctx):
+    """The chain worker uploads its draws into a device slab that is reused from proof to proof; an upload that fails must stop the proof
+    (BPG_ERR_DEVICE), never let s_L, s_R be built from what the slab held before.  The next proof on the context is unaffected."""
+    import ctypes as C
+    a = workloads.mimc_preimage(ctx, nbytes=100, seed=11, label=b"MiMCHash")
+    inst, state = a.prover.instance(), a.transcript.state
+    ctx.gens_ensure(a.gens_capacity)
+    res = ctx.upload(inst)
+    seed = bytes([9]) * 32
+    good, _ = res.prove(state, inst.v_blinding, seed, 0)
+    ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
+    assert res.prove(state, inst.v_blinding, seed, 0)[0] == good          # the stream path, uploads intact
+    assert bpg.lib().bpg_test_fail_next_upload(ctx._h) == 0
+    ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
+    with pytest.raises(bpg.BpgError) as e:
+        res.prove(state, inst.v_blinding, seed, 0)
+    assert e.value.status == 7 and "upload" in str(e.value)
+    assert res.prove(state, inst.v_blinding, seed, 0)[0] == good          # drawn inside the call
+    ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
+    assert res.prove(state, inst.v_blinding, seed, 0)[0] == good
+    res.free()
 
 
 def test_contexts_of_one_device_share_generator_tables(monkeypatch):
