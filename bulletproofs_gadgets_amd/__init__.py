@@ -309,6 +309,11 @@ class Context:
             raise ValueError("v_blinding must be a multiple of 32 bytes")
         _chk(lib().bpg_blinding_begin(self._h, ts, C.c_uint64(len(v_blinding) // 32), v_blinding, _seed32(rng_seed), C.c_uint64(max_multipliers)))
 
+    def attach_chain_pool(self, pool, max_streams=2):
+        """bpg_ctx_attach_chain_pool: this context's blinding streams are drawn by the shared pool (None: back to its own chain worker)."""
+        _chk(lib().bpg_ctx_attach_chain_pool(self._h, pool._h if pool is not None else None, C.c_uint32(max_streams)))
+        self._pool = pool                                     # the pool must outlive the attachment
+
     def set_chain_lanes(self, lanes: int):
         """bpg_ctx_set_chain_lanes: queued blinding streams each chain thread draws in lockstep (1..8; workers * lanes + 1 streams may be alive)."""
         _chk(lib().bpg_ctx_set_chain_lanes(self._h, C.c_uint32(lanes)))
@@ -330,6 +335,28 @@ class Context:
         cs = inst.cstruct()
         _chk(lib().bpg_r1cs_prove(self._h, C.byref(cs), ts, C.c_uint64(inst.m), v_blinding, rng_seed, C.c_uint32(flags), out, C.byref(ln)))
         return out.raw[:ln.value], ts.raw[:203]
+
+
+class ChainPool:
+    """bpg_chain_pool_*: host threads that draw the blinding chains of every context attached to them; lanes[k] = chains thread k draws in lockstep."""
+
+    def __init__(self, lanes):
+        lanes = [int(x) for x in lanes]
+        self._h = C.c_void_p()
+        arr = (C.c_uint32 * len(lanes))(*lanes)
+        _chk(lib().bpg_chain_pool_create(C.c_uint32(len(lanes)), arr, C.byref(self._h)))
+        self.lanes, self.capacity = lanes, sum(lanes)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().bpg_chain_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _verify_flat(ctx, inst, transcript_state, commitments, proof, seed=None, flags=0):

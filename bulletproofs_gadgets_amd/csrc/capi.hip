@@ -408,6 +408,20 @@ bpg_status bpg_blinding_begin(bpg_ctx *ctx, const uint8_t transcript_state[203],
 bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers) { return guard([&] { REQUIRE(ctx); ctx->engine->set_chain_workers(workers); }); }
 bpg_status bpg_ctx_set_chain_lanes(bpg_ctx *ctx, uint32_t lanes) { return guard([&] { REQUIRE(ctx); ctx->engine->set_chain_lanes(lanes); }); }
 int32_t bpg_chain_cpu(bpg_ctx *ctx) { return ctx ? ctx->engine->chain_cpu() : -1; }
+struct bpg_chain_pool { ChainPool *pool; };
+bpg_status bpg_chain_pool_create(uint32_t threads, const uint32_t *lanes, bpg_chain_pool **out) {
+    return guard([&] {
+        REQUIRE(out); *out = nullptr;
+        REQUIRE(threads >= 1 && threads <= 256);
+        std::vector<uint32_t> l(threads, 1u);
+        if (lanes) l.assign(lanes, lanes + threads);
+        *out = new bpg_chain_pool{new ChainPool(l)};
+    });
+}
+void bpg_chain_pool_destroy(bpg_chain_pool *pool) { if (pool) { delete pool->pool; delete pool; } }
+bpg_status bpg_ctx_attach_chain_pool(bpg_ctx *ctx, bpg_chain_pool *pool, uint32_t max_streams) {
+    return guard([&] { REQUIRE(ctx); ctx->engine->attach_chain_pool(pool ? pool->pool : nullptr, pool ? max_streams : 1u); });
+}
 
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t seed[32], uint32_t flags, uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings) {
     return guard([&] {

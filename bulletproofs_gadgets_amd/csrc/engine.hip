@@ -359,11 +359,13 @@ struct Engine::Impl {
     struct ChainWorker {                                     // the context's chain threads: one by default, `workers` draw queued streams side by side
         std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
         std::deque<std::shared_ptr<BlindStream>> pending; bool quit = false;
-        uint32_t lanes = 1;                                  // streams one thread draws in lockstep (merlin.hpp strobe_rng_bulk64_x8); set before the threads start
+        uint32_t lanes = 1;                                  // streams one thread of a context's own worker draws in lockstep (merlin.hpp strobe_rng_bulk64_x8); set before the threads start
+        bool pool = false;                                   // a ChainPool shared by several contexts (its threads carry their own lane counts and outlive the contexts)
+        void stop() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); for (std::thread &t : th) if (t.joinable()) t.join(); th.clear(); }
         // One thread, up to eight streams in lockstep: the sponges of eight proofs in the eight 64-bit lanes of ZMM registers cost a Zen 5 core
         // 193 ns per draw of all eight against 152 ns for one alone (tools/diag/chain_lanes.py): a chain still takes 0.3 - 0.4 s, a core's chain
         // THROUGHPUT goes up sixfold.  Streams join at 4,096-draw boundaries as they are queued and leave when they are complete or stopped.
-        static void run_lanes(ChainWorker *w) {
+        static void run_lanes(ChainWorker *w, uint32_t lanes) {
             struct Lane { std::shared_ptr<BlindStream> b; TranscriptRng rng; uint64_t pos, up; };
             std::vector<Lane> act;
             auto upload = [](Lane &L, uint64_t to) {
@@ -381,7 +383,7 @@ struct Engine::Impl {
                 {   // take what is queued; wait only when there is nothing to draw
                     std::unique_lock<std::mutex> lk(w->mu);
                     if (act.empty()) { w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; }
-                    while (act.size() < w->lanes && !w->pending.empty()) {
+                    while (act.size() < lanes && !w->pending.empty()) {
                         std::shared_ptr<BlindStream> b = w->pending.front(); w->pending.pop_front();
                         b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
                         act.push_back(Lane{b, b->snaps[0], 0, 0});
@@ -404,8 +406,8 @@ struct Engine::Impl {
                 for (Lane &L : act) { L.pos += BlindStream::SNAP; if (L.pos % BlindStream::UP == 0) upload(L, L.pos); }
             }
         }
-        static void run(ChainWorker *w) {
-            if (w->lanes > 1) { run_lanes(w); return; }
+        static void run(ChainWorker *w, uint32_t lanes) {
+            if (lanes > 1) { run_lanes(w, lanes); return; }
             for (;;) {
                 std::shared_ptr<BlindStream> b;
                 { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
@@ -435,7 +437,8 @@ struct Engine::Impl {
             }
         }
     };
-    std::unique_ptr<ChainWorker> chain;
+    std::shared_ptr<ChainWorker> chain;                     // the context's own worker, or the ChainPool it is attached to
+    uint32_t pool_streams = 0;                              // attached to a pool: blinding streams this context may have alive
     uint32_t chain_workers = 1;                             // threads of the chain worker (bpg_ctx_set_chain_workers / BPG_CHAIN_WORKERS); alive streams <= workers * lanes + 1
     uint32_t chain_lanes = 1;                               // streams each thread draws in lockstep (bpg_ctx_set_chain_lanes / BPG_CHAIN_LANES, 1..8)
     std::deque<std::shared_ptr<BlindStream>> blinds;        // alive streams, oldest first
@@ -463,10 +466,8 @@ struct Engine::Impl {
     void chain_shutdown() {
         blind_cancel();
         if (!chain) return;
-        { std::lock_guard<std::mutex> lk(chain->mu); chain->quit = true; }
-        chain->cv.notify_all();
-        for (std::thread &t : chain->th) if (t.joinable()) t.join();
-        chain.reset();
+        if (!chain->pool) chain->stop();                    // a pool's threads go on serving the other contexts
+        chain.reset(); pool_streams = 0;
     }
     uint64_t gens_cap = 0;
     // BPG_GENS_CACHE_DIR (see gens_cache_path): load = read + checksum + upload + compare 2 x 64 sampled points with points derived afresh from
@@ -1284,7 +1285,7 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     Impl &I = *impl_;
     if (max_multipliers == 0) { I.blind_cancel(); return; }
     using BS = Impl::BlindStream;
-    const size_t max_alive = (size_t)I.chain_workers * I.chain_lanes + 1;
+    const size_t max_alive = I.pool_streams ? I.pool_streams : (size_t)I.chain_workers * I.chain_lanes + 1;
     while (I.blinds.size() >= max_alive) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // the oldest gives way
     auto b = std::make_shared<BS>();
     Transcript T = after_commitments;
@@ -1317,10 +1318,27 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
     I.slab_owner[slot] = b;
     I.blinds.push_back(b);
-    if (!I.chain) { I.chain = std::make_unique<Impl::ChainWorker>(); I.chain->lanes = I.chain_lanes; (void)keccak_impl(); }
-    while (I.chain->th.size() < I.chain_workers) I.chain->th.emplace_back(Impl::ChainWorker::run, I.chain.get());
+    if (!I.chain) { I.chain = std::make_shared<Impl::ChainWorker>(); I.chain->lanes = I.chain_lanes; (void)keccak_impl(); }
+    if (!I.chain->pool) while (I.chain->th.size() < I.chain_workers) I.chain->th.emplace_back(Impl::ChainWorker::run, I.chain.get(), I.chain->lanes);
     { std::lock_guard<std::mutex> lk(I.chain->mu); I.chain->pending.push_back(b); }
     I.chain->cv.notify_one();
+}
+// ChainPool: chain threads shared by the contexts attached to it (engine.hpp)
+struct ChainPool::Impl { std::shared_ptr<Engine::Impl::ChainWorker> w; };
+ChainPool::ChainPool(const std::vector<uint32_t> &lanes_per_thread) : impl_(new Impl()) {
+    if (lanes_per_thread.empty() || lanes_per_thread.size() > 256) { delete impl_; throw std::invalid_argument("chain pool: 1..256 threads"); }
+    for (uint32_t l : lanes_per_thread) if (l < 1 || l > 8) { delete impl_; throw std::invalid_argument("chain pool: 1..8 lanes per thread"); }
+    impl_->w = std::make_shared<Engine::Impl::ChainWorker>();
+    impl_->w->pool = true;
+    (void)keccak_impl();
+    for (uint32_t l : lanes_per_thread) { impl_->w->th.emplace_back(Engine::Impl::ChainWorker::run, impl_->w.get(), l); capacity_ += l; }
+}
+ChainPool::~ChainPool() { impl_->w->stop(); delete impl_; }
+void Engine::attach_chain_pool(ChainPool *pool, uint32_t max_streams) {
+    impl_->chain_shutdown();                                  // streams in flight are dropped
+    if (!pool) return;
+    if (max_streams < 1 || max_streams > 64) throw std::invalid_argument("chain pool: 1..64 streams per context");
+    impl_->chain = pool->impl_->w; impl_->pool_streams = max_streams;
 }
 void Engine::set_chain_workers(uint32_t n) {
     if (n < 1 || n > 64) throw std::invalid_argument("chain workers: 1..64");

@@ -30,6 +30,22 @@ struct EngineConfig {
     std::string gens_cache_dir;     // empty unset (BPG_GENS_CACHE_DIR, else no cache)
 };
 
+// Chain threads shared by several contexts (include/bpg.h bpg_chain_pool_*): thread k draws up to lanes_per_thread[k] queued blinding streams in
+// lockstep, whichever attached context queued them.  Must outlive the contexts attached to it.
+class ChainPool {
+public:
+    explicit ChainPool(const std::vector<uint32_t> &lanes_per_thread);
+    ~ChainPool();
+    ChainPool(const ChainPool &) = delete;
+    ChainPool &operator=(const ChainPool &) = delete;
+    uint32_t capacity() const { return capacity_; }          // chains the pool draws side by side
+    struct Impl;
+private:
+    friend class Engine;
+    Impl *impl_;
+    uint32_t capacity_ = 0;
+};
+
 class Engine {
 public:
     explicit Engine(int device, const EngineConfig &cfg = EngineConfig());
@@ -60,6 +76,8 @@ public:
     void blinding_cancel();
     // threads of the context's chain worker: that many queued streams are drawn side by side, workers + 1 may be alive (default 1)
     void set_chain_workers(uint32_t n);
+    // draw this context's blinding streams on a shared pool instead of its own worker (nullptr: back to its own); max_streams of them may be alive
+    void attach_chain_pool(ChainPool *pool, uint32_t max_streams);
     void set_chain_lanes(uint32_t n);        // streams each chain thread draws in lockstep (1..8; eight sponges in the lanes of ZMM registers)
     void test_fail_next_upload();   // test hook (bpg_test_fail_next_upload)
     uint64_t table_bytes() const;   // precomputed generator multiples held on this device by the process

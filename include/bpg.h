@@ -228,6 +228,15 @@ bpg_status bpg_ctx_set_chain_workers(bpg_ctx *ctx, uint32_t workers);
  * up to eight chains going - a chain alone gets ~25 % slower, a core's chain throughput six times higher; workers * lanes + 1 streams may be alive.
  * Streams in flight are dropped by this call, like bpg_ctx_set_chain_workers. */
 bpg_status bpg_ctx_set_chain_lanes(bpg_ctx *ctx, uint32_t lanes);
+/* A chain pool: host threads that draw the blinding chains of EVERY context attached to it, thread k up to lanes[k] (1..8) of them in lockstep.  A
+ * host that proves on several contexts of a GPU (proving streams) sizes ONE pool for its cores instead of a worker per context: e.g. 14 threads with
+ * one lane (a chain alone takes 0.30 s at 2^20) and one thread with 6 lanes (0.38 s each) draw twenty chains at once on 15 cores.  An attached
+ * context may have max_streams blinding streams alive (bpg_blinding_begin retires the oldest beyond that); bpg_ctx_set_chain_workers / _lanes detach.
+ * The pool must outlive its contexts' use of it: detach (pool = NULL) or destroy the contexts first. */
+typedef struct bpg_chain_pool bpg_chain_pool;
+bpg_status bpg_chain_pool_create(uint32_t threads, const uint32_t *lanes /* threads entries, NULL = 1 each */, bpg_chain_pool **out);
+void bpg_chain_pool_destroy(bpg_chain_pool *pool);
+bpg_status bpg_ctx_attach_chain_pool(bpg_ctx *ctx, bpg_chain_pool *pool /* NULL = detach */, uint32_t max_streams);
 int32_t bpg_chain_cpu(bpg_ctx *ctx);   /* diagnostics: host core the chain worker last ran on, -1 = no stream drawn yet */
 bpg_status bpg_prover_prove(bpg_prover *p, uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags,
                             uint8_t *proof_out, uint64_t *proof_len, bpg_timings *timings);

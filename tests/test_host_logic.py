@@ -324,3 +324,29 @@ def test_profile_tooling_on_synthetic_counter_files(tmp_path):
     assert abs(sweep["hbm_bytes_per_launch"] - (200 * 1024 * 960.0 / 1024.0 + 4 * 1024)) < 1e-6
     assert abs(poly["hbm_bytes_per_launch"] - (10 * 1024 * 2.0 + 2 * 1024)) < 1e-6
     assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+
+
+def test_host_thread_planning_on_synthetic_topologies():
+    """bench.py sizes the chain threads of a rank for the cores it really has (cores_for_rank) and deals the first chains of all its proving
+    streams to them (plan_chain_pool): every chain thread gets a core to itself, two cores stay free, lockstep threads only where cores run out."""
+    import bench
+    # an 8-GPU host, 2 NUMA nodes of 64 cores, 4 ranks on each: 16 cores per rank -> 13 single-lane threads + one with 7 lanes for 20 streams
+    assert bench.cores_for_rank(64, 4) == 16
+    lanes = bench.plan_chain_pool(16, 20)
+    assert lanes == [1] * 13 + [7] and len(lanes) <= 16 - 2
+    # the same host under a cgroup quota of 64 CPUs for the whole job: 8 per rank
+    assert bench.cores_for_rank(64, 4, quota=32) == 8
+    lanes = bench.plan_chain_pool(8, 20)
+    assert sum(lanes) == 20 and len(lanes) == 6 and max(lanes) <= 8 and lanes[:4] == [1] * 4
+    # 8 ranks on one 32-core node: 4 cores per rank, two chain threads with 8 lanes each; four chains of twenty wait for the second wave
+    assert bench.cores_for_rank(32, 8) == 4
+    assert bench.plan_chain_pool(4, 20) == [8, 8]
+    # a one-GPU box that shows 256 CPUs but is throttled to 16
+    assert bench.cores_for_rank(128, 1, quota=16) == 16
+    # plenty of cores: one lane per stream, never more threads than streams
+    assert bench.plan_chain_pool(64, 20) == [1] * 20 and bench.plan_chain_pool(64, 3) == [1] * 3
+    for cores in range(1, 40):
+        for n in (1, 2, 3, 8, 14, 20, 33):
+            lanes = bench.plan_chain_pool(cores, n)
+            assert lanes and all(1 <= x <= 8 for x in lanes) and len(lanes) <= max(1, cores - 2) and sum(lanes) <= n
+            assert sum(lanes) == n or sum(lanes) >= 8 * max(1, cores - 2) - 7      # short only when the cores cannot carry n chains at all
