@@ -216,9 +216,10 @@ struct Engine::Impl {
     DevBuf gens;                                // view of shared->gens (not owned)
     DevBuf bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, chunk_key, digits, entries1, starts1;
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, digits, entries1, starts1;
     uint32_t sort_levels = 2;       // 2 = two-level sort (digits -> coarse partition -> fine sort per bin), 1 = one-level tile sort (BPG_MSM_SORT)
     uint32_t tile_shift = 6, tile_lgmax = 14, tile_threads = 256;   // sort tiles: 2^-tile_shift of an MSM's terms, at most 2^tile_lgmax (BPG_TILE_SHIFT, BPG_TILE_LGMAX, BPG_TILE_THREADS)
+    uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 256 CUs x 4 (BPG_SWEEP_RESIDENT)
     uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
@@ -545,6 +546,8 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (impl_->gens_cache_dir.empty()) { if (const char *e = std::getenv("BPG_GENS_CACHE_DIR")) impl_->gens_cache_dir = e; }
     // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
     if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) impl_->sweep_blocks_resident = (uint32_t)cus * 4u; }
+    if (const char *e = std::getenv("BPG_SWEEP_RESIDENT")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) impl_->sweep_blocks_resident = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_MSM_SORT")) { int v = std::atoi(e); if (v == 1 || v == 2) impl_->sort_levels = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_SHIFT")) { int v = std::atoi(e); if (v >= 0 && v <= 10) impl_->tile_shift = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
@@ -586,7 +589,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->chunk_key, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
@@ -863,12 +866,20 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     entries.ensure((size_t)(total ? total : 1) * W * 4);
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
-    uint32_t lgCH = 5;                                          // balanced sweep: 2^lgCH sorted entries per thread
-    if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 3 && v <= 10) lgCH = (uint32_t)v; }
+    // balanced sweep: CH sorted entries per thread.  About 32, adjusted so that the launch's blocks fill the device a whole number of times: the
+    // sweep keeps sweep_blocks_resident blocks of 256 threads on the CUs at once (4 waves per SIMD at its register count), and 4.25 rounds of
+    // blocks cost what 5 do.  BPG_LGCH pins a power of two instead (diagnostics).
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
-    const uint32_t nchunks = cdiv(Mub ? Mub : 1, 1u << lgCH);
+    uint32_t CH = 32;
+    if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 2 && v <= 10) CH = 1u << v; }
+    else {
+        const uint64_t slots = (uint64_t)sweep_blocks_resident * 256;
+        uint64_t rounds = (Mub + slots * 16) / (slots * 32);    // nearest whole number of rounds at 32 entries per thread
+        if (rounds < 1) rounds = 1;
+        CH = (uint32_t)std::max<uint64_t>(4, (Mub + slots * rounds - 1) / (slots * rounds));
+    }
+    const uint32_t nchunks = cdiv(Mub ? Mub : 1, CH);
     heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
-    chunk_key.ensure((size_t)nchunks * 4); P.lgCH = lgCH;
     if (two_level) {
         // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
         const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
@@ -885,34 +896,33 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk1);
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
         if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits.as<uint16_t>(), total, starts1.as<uint32_t>(), entries1.as<uint32_t>());
-        BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(),
-                   chunk_key.as<uint32_t>());
+        BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     } else {
         counts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
         blocksum.ensure((size_t)(nblocks + 1) * 4);
         tile_hist.ensure((size_t)nmsm * W * P.tmax * nb * 4);
         plain.ensure((size_t)(total ? total : 1) * 32);
         if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
-        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
         BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>());
+        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     }
     {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
-        BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(), chunk_key.as<uint32_t>(),
-                   buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH);
+        BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(),
+                   buckets.as<ge_ext>(), slotA, slotB, nkeys, CH);
         // roofline bookkeeping.  Algorithmic bytes: the information content of the MSM this launch sweeps, one scalar + one
         // point = 64 B per TERM, counted once however many windows the term is cut into.  Device bytes: every (term, window) entry is a
         // 4-byte index and a 96-byte affine Niels point.  Work: one mixed addition (7 field multiplications) per entry; Mub counts zero
         // digits too (probability 2^-c each for full-width scalars).
         prof_note(KID_k_bucket_chunks, 64.0 * (double)total, 100.0 * (double)Mub, 7.0 * (double)Mub);
-        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, lgCH, heavy.as<uint32_t>());
-        BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, lgCH, heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, CH, heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, CH, heavy.as<uint32_t>());
     }
     const uint32_t nred = nmsm * W * nsegpw;
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);

@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
-    uint32_t nmsm, W, nb, lgTile, tmax, lgCH;
+    uint32_t nmsm, W, nb, lgTile, tmax;
     uint32_t fb, CB;             // two-level sort: a bucket index splits into CB coarse bins x 2^fb fine slots (nb = CB << fb)
     uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
     uint32_t tile_start[5];      // first tile of MSM m
@@ -57,11 +57,9 @@ __global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_
     plain[2 * (size_t)g] = make_uint4(w[0], w[1], w[2], w[3]);
     plain[2 * (size_t)g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-// pass 1 also notes, for every chunk of 2^lgCH sorted entries, the key of the chunk's first entry (chunk_key): k_bucket_chunks starts
-// from it instead of searching starts[]
 template <int PASS>
 __global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
-                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
+                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
     extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
     const uint32_t T = blockIdx.x, win = blockIdx.y;
     uint32_t m = 0;
@@ -87,7 +85,6 @@ __global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const u
         else {
             const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
             const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i;
-            if ((pos & ((1u << P.lgCH) - 1u)) == 0) chunk_key[pos >> P.lgCH] = mw * P.nb + mag - 1;
         }
     }
     if (PASS == 0) {
@@ -105,8 +102,8 @@ __global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const u
 //   k_msm_scatter1  block (tile, window): orders its entries by coarse bin in LDS and copies the runs out - consecutive lanes write
 //                   consecutive addresses; entry = neg << 31 | fine << (31 - fb) | segment << (28 - fb) | index in segment
 //   k_msm_sort2     block per coarse bin: counting sort by the fb fine bits inside the bin's own range (LDS counters, the range is written
-//                   by this block only, so its lines are completed in the XCD's L2), emits starts[] per bucket and chunk_key[]
-// The result is exactly what the one-level sort produces (entries grouped by bucket, starts[], chunk_key[]); the sweep is unchanged.
+//                   by this block only, so its lines are completed in the XCD's L2), emits starts[] per bucket
+// The result is exactly what the one-level sort produces (entries grouped by bucket, starts[]); the sweep is unchanged.
 // LDS counter increment that does not serialise when every lane of the wave holds the same key (identical scalars in consecutive terms:
 // padding generators, repeated witness values, range-proof bits): one atomic per wave then.  Returns the lane's slot.
 __device__ __forceinline__ uint32_t msm_lds_take(uint32_t *ctr, uint32_t key, bool active) {
@@ -218,7 +215,7 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
 // the grand total).  Counting sort by the fine bits; the bin's range of `entries` is written by this block alone.
 #define MSM_STASH 16384
 __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__restrict__ starts1, uint32_t nflat, const uint32_t *__restrict__ entries1,
-                                                   uint32_t *__restrict__ starts, uint32_t *__restrict__ entries, uint32_t *__restrict__ chunk_key) {
+                                                   uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
     __shared__ uint32_t cnt[128];
     __shared__ uint32_t cur[128];
     __shared__ uint16_t slot16[MSM_STASH];                   // the slot each entry took in its bucket (bins of up to MSM_STASH entries: one atomic pass)
@@ -254,7 +251,7 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
         if (k + 1 == K && lane == 0) starts[(size_t)K * nf] = s1;
     }
     __syncthreads();
-    const uint32_t idxbits = 28u - P.fb, imask = (1u << idxbits) - 1u, chmask = (1u << P.lgCH) - 1u;
+    const uint32_t idxbits = 28u - P.fb, imask = (1u << idxbits) - 1u;
     for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
         uint32_t vv[4];
 #pragma unroll
@@ -265,10 +262,7 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
             const bool on = e < s1;
             const uint32_t v = vv[u], f = (v >> fsh) & fmask;
             const uint32_t pos = stash ? (on ? cur[f] + slot16[e - s0] : 0u) : msm_lds_take(cur, f, on);
-            if (on) {
-                entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
-                if ((pos & chmask) == 0u) chunk_key[pos >> P.lgCH] = k * nf + f;
-            }
+            if (on) entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
         }
     }
 }
@@ -338,33 +332,50 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 // [c*CH, (c+1)*CH) whatever buckets it crosses, so a bucket that received thousands of terms (identical scalars: the -y^h
 // padding terms of the first IPA round, repeated witness values, range-proof bits) is spread over many threads instead of
 // serialising one.  A bucket that lies inside one chunk is stored directly; a bucket that crosses chunk boundaries leaves
-// one partial per chunk (slotA = piece at the chunk's beginning, slotB = piece at its end) for k_bucket_combine.
+// one partial per chunk (slotA = the piece of a bucket that began in an earlier chunk, slotB = the piece of a bucket that begins here and
+// goes on) for k_bucket_combine.  CH is any length (not a power of two): the host picks it so that the blocks of a launch fill the CUs
+// a whole number of times (engine.hip Impl::msm) - with 2^5 entries per chunk the 4,352 blocks of a 2^21-term launch were 4.25 rounds of the
+// 1,024 blocks the device holds, and the last quarter round ran on a quarter of the machine.
 // bucket that holds sorted entry e: the k >= klo with starts[k] <= e < starts[k+1]  (upper_bound - 1)
 __device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ starts, uint32_t nkeys, uint32_t e, uint32_t klo) {
     uint32_t lo = klo, hi = nkeys + 1;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e) lo = mid + 1; else hi = mid; }
     return lo - 1;
 }
+// q = +-P for the affine Niels point at `base` (y+x, y-x, 2dxy): a subtraction exchanges the first two (picked by ADDRESS: no select) and
+// the sign of the third, which is the same as exchanging F and G of the addition formulas
+__device__ __forceinline__ ge_ext ge_madd_swapped(const ge_ext &p, const fe &qp, const fe &qm, const fe &t2d, uint32_t neg) {
+    fe A = fe_mul(fe_sub(p.Y, p.X), qm);
+    fe B = fe_mul(fe_add(p.Y, p.X), qp);
+    fe C = fe_mul(p.T, t2d);
+    fe D = fe_add(p.Z, p.Z);
+    fe E = fe_sub(B, A), F0 = fe_sub(D, C), G0 = fe_add(D, C), H = fe_add(B, A);
+    const fe F = fe_select(F0, G0, neg), G = fe_select(G0, F0, neg);
+    ge_ext r; r.X = fe_mul(E, F); r.Y = fe_mul(G, H); r.T = fe_mul(E, H); r.Z = fe_mul(F, G);
+    return r;
+}
 __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
-                                                       const uint32_t *__restrict__ chunk_key, ge_ext *__restrict__ buckets,
-                                                       ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB, uint32_t nkeys, uint32_t lgCH) {
+                                                       ge_ext *__restrict__ buckets, ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB,
+                                                       uint32_t nkeys, uint32_t CH) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t e0 = c << lgCH;
+    const uint64_t e0w = (uint64_t)c * CH;
     const uint32_t M = starts[nkeys];                      // true entry count (zero digits were skipped)
-    if (e0 >= M) return;
-    const uint32_t e1 = (e0 + (1u << lgCH) < M) ? e0 + (1u << lgCH) : M;
-    uint32_t k = chunk_key[c], kstart = starts[k], kend = starts[k + 1], seg_begin = e0;
+    if (e0w >= M) return;
+    const uint32_t e0 = (uint32_t)e0w;
+    const uint32_t e1 = (e0w + CH < M) ? e0 + CH : M;
+    uint32_t k = msm_bucket_of(starts, nkeys, e0, 0), kstart = starts[k], kend = starts[k + 1];
     uint32_t kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];   // end of the next bucket, loaded one boundary ahead of its use
     uint32_t ent = entries[e0];
     ge_ext acc = ge_identity();
     for (uint32_t e = e0; e < e1; e++) {
         const uint32_t sg = (ent >> 27) & 7u, neg = ent >> 31;
-        const ge_niels q = S.pts[sg][msm_point_index(S, sg, ent & 0x07ffffffu)];
+        const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
+        const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];   // issued before the bookkeeping below
         if (e + 1 < e1) ent = entries[e + 1];
         if (e >= kend) {
-            if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
-            else { if (seg_begin == e0) slotA[c] = acc; /* a piece ending inside the chunk cannot also end it */ }
-            acc = ge_identity(); seg_begin = e;
+            if (kstart >= e0) buckets[k] = acc;              // began in this chunk and ends in it
+            else slotA[c] = acc;                             // the piece of a bucket that began in an earlier chunk (at most one per chunk: the first)
+            acc = ge_identity();
             k++; kstart = kend; kend = kend2;
             if (e >= kend) {                                 // a run of empty buckets (half of a 15-bit window is structurally
                 k = msm_bucket_of(starts, nkeys, e, k + 1);  // empty): search instead of walking it with dependent loads
@@ -372,10 +383,11 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
             }
             kend2 = starts[k + 2 <= nkeys ? k + 2 : nkeys];
         }
-        acc = ge_madd_signed(acc, q, neg);
+        acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
     }
-    if ((kstart >> lgCH) == ((kend - 1) >> lgCH)) buckets[k] = acc;
-    else { if (seg_begin == e0) slotA[c] = acc; if (kend >= e1) slotB[c] = acc; }
+    if (kstart >= e0 && kend <= e1) buckets[k] = acc;
+    else if (kstart < e0) slotA[c] = acc;                    // a bucket that began earlier (and may go on beyond this chunk)
+    else slotB[c] = acc;                                     // begins here and goes on
 }
 
 // one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] for a
@@ -384,12 +396,12 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
 #define HEAVY_CHUNKS 32
 __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                         const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
-                                                        uint32_t nkeys, uint32_t lgCH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
+                                                        uint32_t nkeys, uint32_t CH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
     const uint32_t s0 = starts[k], s1 = starts[k + 1];
     if (s0 == s1) { buckets[k] = ge_identity(); return; }
-    const uint32_t c0 = s0 >> lgCH, c1 = (s1 - 1) >> lgCH;
+    const uint32_t c0 = s0 / CH, c1 = (s1 - 1) / CH;
     if (c0 == c1) return;
     if (c1 - c0 > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
     ge_ext acc = slotB[c0];
@@ -399,13 +411,13 @@ __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restri
 // one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS
 __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                               const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
-                                                              uint32_t lgCH, const uint32_t *__restrict__ heavy) {
+                                                              uint32_t CH, const uint32_t *__restrict__ heavy) {
     __shared__ ge_ext lds[256];
     const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     ge_ext *L = lds + wv * 64;
     for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {      // wave-uniform trip count; no block barrier inside
         const uint32_t k = heavy[1 + it];
-        const uint32_t c0 = starts[k] >> lgCH, c1 = (starts[k + 1] - 1) >> lgCH;
+        const uint32_t c0 = starts[k] / CH, c1 = (starts[k + 1] - 1) / CH;
         ge_ext acc = lane == 0 ? slotB[c0] : ge_identity();
         for (uint32_t c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, slotA[c]);
         L[lane] = acc;
