@@ -2,6 +2,11 @@
 
     python -m bulletproofs_gadgets_amd.cli prover   NAME      reads NAME.gadgets/.inst/.wtns, writes NAME.coms/.proof
     python -m bulletproofs_gadgets_amd.cli verifier NAME      reads NAME.gadgets/.inst/.coms/.proof, prints true/false
+    python -m bulletproofs_gadgets_amd.cli prover|verifier --batch FILE [--gpus N]
+        FILE lists one NAME per line: a batch of independent proofs (the reference's own batch is its CI workflow, prover then verifier over twelve stems:
+        .github/workflows/integration_tests.yml:19-58).  One process per GPU; rank r takes stems r, r + N, ... and runs the driver above on each with
+        ONE engine context (generators and tables derived once per rank), writes its own .coms/.proof; the finished proof bytes (verifier: the
+        verdicts) are gathered over RCCL and rank 0 prints one summary line per stem.  Same files as N = 1 and as one run per stem.
 
 Mirrors reference src/bin/prover.rs:47-100 and src/bin/verifier.rs:46-101 : the transcript label is the NAME argument (prover.rs:49-52); witnesses are committed in .wtns order and
 written as "C{id}-{k} = 0x.." (assignment_parser.rs:152-169,213-220); derived commitments as "D{line}-{sub}-{k}";
@@ -439,8 +444,112 @@ def verifier(name, ctx=None, flags=0, quiet=False):
     return ok
 
 
+def read_batch(path):
+    """stems of a batch file: one per line, blank lines and # comments skipped"""
+    with open(path) as f:
+        return [l.strip() for l in f if l.strip() and not l.lstrip().startswith("#")]
+
+
+def spawn_batch_ranks(mode, batch_file, gpus):
+    """`--gpus N` without a torchrun environment: start N ranks of this module (fresh processes, before anything touches the GPU)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "bulletproofs_gadgets_amd.cli", mode, "--batch", batch_file, "--gpus", str(gpus)]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_batch(mode, batch_file, gpus=1, seed=None, rng_seed=None, out=sys.stdout):
+    """One rank of a batch (the whole batch when gpus == 1).  Returns the list of per-stem results in file order on every rank:
+    prover: (stem, constraints, proof bytes); verifier: (stem, bool)."""
+    stems = read_batch(batch_file)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != gpus:
+        raise SystemExit("cli --batch: --gpus %d but WORLD_SIZE=%d (one rank per GPU; without torchrun the driver spawns them itself)" % (gpus, world))
+    dist, coll_device, device = None, "cpu", 0
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("BPG_BATCH_BACKEND", "nccl")              # gloo: rehearsal on fewer GPUs than ranks (the ranks then share devices)
+        ndev = torch.cuda.device_count()
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if backend == "nccl":
+            if world > ndev:
+                raise SystemExit("cli --batch: %d ranks but %d GPUs (BPG_BATCH_BACKEND=gloo rehearses on fewer)" % (world, ndev))
+            device, coll_device = local_rank, "cuda"
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            device = local_rank % max(ndev, 1)
+            dist.init_process_group(backend)
+    from .batch import gather_proofs, shard_indices
+    ctx = Context(device)
+    mine = shard_indices(len(stems), rank, world)
+    local = {}
+    for i in mine:
+        if mode == "prover":
+            p, proof = prover(stems[i], ctx, seed=seed, rng_seed=rng_seed, quiet=True)
+            local[i] = (p.num_constraints(), proof)
+        else:
+            local[i] = verifier(stems[i], ctx, quiet=True)
+    if mode == "prover":
+        # the finished proofs cross the fabric as fixed-size records: constraints (8 B) | length (4 B) | proof bytes, padded to the longest proof of the batch
+        longest = max([len(pr) for _, pr in local.values()] or [0])
+        if dist is not None:
+            import torch
+            t = torch.tensor([longest], dtype=torch.int64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            longest = int(t.item())
+        rec_len = 12 + longest
+        recs = {i: q.to_bytes(8, "little") + len(pr).to_bytes(4, "little") + pr + bytes(longest - len(pr)) for i, (q, pr) in local.items()}
+        allrecs = gather_proofs(recs, len(stems), rec_len, dist, device=coll_device)
+        results = []
+        for stem, r in zip(stems, allrecs):
+            n = int.from_bytes(r[8:12], "little")
+            results.append((stem, int.from_bytes(r[:8], "little"), r[12:12 + n]))
+        if rank == 0:
+            for stem, q, pr in results:
+                out.write("%s: %d constraints, %d-byte proof, sha256 %s\n" % (stem, q, len(pr), hashlib.sha256(pr).hexdigest()[:16]))
+    else:
+        recs = {i: bytes([1 if ok else 0]) for i, ok in local.items()}
+        allrecs = gather_proofs(recs, len(stems), 1, dist, device=coll_device)
+        results = [(stem, r == b"\x01") for stem, r in zip(stems, allrecs)]
+        if rank == 0:
+            for stem, ok in results:
+                out.write("%s: %s\n" % (stem, "true" if ok else "false"))
+    out.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return results
+
+
 def main(argv=None):
     argv = argv if argv is not None else sys.argv[1:]
+    if "--batch" in argv:
+        gpus = 1
+        ok = len(argv) in (3, 5) and argv[0] in ("prover", "verifier") and argv[1] == "--batch"
+        if ok and len(argv) == 5:
+            ok = argv[3] == "--gpus" and argv[4].isdigit() and int(argv[4]) >= 1
+            gpus = int(argv[4]) if ok else 1
+        if not ok:
+            print(__doc__)
+            return 2
+        if gpus > 1 and "WORLD_SIZE" not in os.environ:
+            return spawn_batch_ranks(argv[0], argv[2], gpus)
+        # tests pin the randomness the way the native driver does (csrc/cli_main.cpp): BPG_CLI_SEED = blinding stream, BPG_CLI_RNG_SEED = hex rng seed
+        seed = os.environ["BPG_CLI_SEED"].encode() if "BPG_CLI_SEED" in os.environ else None
+        rng_seed = bytes.fromhex(os.environ["BPG_CLI_RNG_SEED"]).ljust(32, b"\0")[:32] if "BPG_CLI_RNG_SEED" in os.environ else None
+        res = run_batch(argv[0], argv[2], gpus, seed=seed, rng_seed=rng_seed)
+        return 0 if argv[0] == "prover" or all(ok for _, ok in res) else 1
     if len(argv) != 2 or argv[0] not in ("prover", "verifier"):
         print(__doc__)
         return 2

@@ -163,6 +163,7 @@ bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config, bpg_ctx *
     return guard([&] { REQUIRE(out); *out = nullptr; Engine *e = new Engine(device, engine_config(config)); *out = new bpg_ctx{e}; });
 }
 bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out) { return bpg_ctx_create_ex(device, nullptr, out); }
+int32_t bpg_device_count(void) { return Engine::device_count(); }
 bpg_status bpg_test_fail_next_upload(bpg_ctx *ctx) { return guard([&] { REQUIRE(ctx); ctx->engine->test_fail_next_upload(); }); }
 uint64_t bpg_table_bytes(bpg_ctx *ctx) { return ctx ? ctx->engine->table_bytes() : 0; }
 void bpg_ctx_destroy(bpg_ctx *ctx) { if (ctx) { delete ctx->engine; delete ctx; } }

@@ -4,6 +4,12 @@
 //     bpg_prover   NAME    reads NAME.gadgets / NAME.inst / NAME.wtns, writes NAME.coms / NAME.proof, prints #constraints
 //     bpg_verifier NAME    reads NAME.gadgets / NAME.inst / NAME.coms / NAME.proof, prints true|false, exit code 0|1
 //
+//     bpg_prover | bpg_verifier --batch FILE [--gpus N]
+//                          FILE lists one NAME per line - a batch of independent proofs (the reference's own batch is its CI workflow, prover then
+//                          verifier over twelve stems: .github/workflows/integration_tests.yml:19-58).  One process per GPU (the command starts them
+//                          itself, before it touches the GPU); rank r takes stems r, r + N, ... with ONE engine context, writes their files and
+//                          reports to the parent, which prints one summary line per stem in file order.  Same files as N = 1 and as one run per stem.
+//
 // One executable, dispatched on argv[0] (or on a first argument "prover" / "verifier").  Grammar: the seven gadget lines of
 // src/lalrpop/gadget_grammar.lalrpop:6-85 plus OR [ { .. } { .. } ] blocks (prover.rs:202-238, verifier.rs:162-186).
 // Blinding factors: 64 bytes of /dev/urandom reduced mod l per factor (the reference uses thread_rng()); with BPG_CLI_SEED set they
@@ -21,6 +27,8 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "../../include/bpg.h"
 
 namespace {
@@ -212,6 +220,8 @@ struct ProverRun {
     std::string name; bpg_ctx *ctx = nullptr; bpg_transcript *tr = nullptr; bpg_prover *p = nullptr;
     std::map<std::string, Bytes> instance; std::map<std::string, Witness> witness; std::vector<std::string> coms_lines, lines;
     Blindings rnd;
+    bool own_ctx = true, quiet = false;              // batch mode: the rank's context is shared by its stems, results go to the summary
+    uint64_t out_constraints = 0, out_proof_len = 0;
     int pass = 0;                                    // 0: single pass (commit and assemble line by line); 1: commitments only; 2: assembly only
     std::vector<Setup> cache; size_t cache_pos = 0;  // the commitments of pass 1 in the order pass 2 asks for them
     uint64_t est_multipliers = 0; bool saw_or = false;
@@ -357,7 +367,7 @@ struct ProverRun {
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t0 = now();
         auto lap = [&](const char *what) { if (timing) { double t1 = now(); std::fprintf(stderr, "  %-28s %8.2f ms\n", what, t1 - t0); t0 = t1; } };
-        chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
+        if (!ctx) chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
         lap("context (HIP init, bases)");
         chk(bpg_transcript_new(reinterpret_cast<const uint8_t *>(name.data()), name.size(), &tr), "Transcript::new");
         chk(bpg_prover_new(ctx, tr, &p), "Prover::new");
@@ -389,7 +399,8 @@ struct ProverRun {
             if (cache_pos != cache.size()) fail("two-pass driver: pass 2 did not use every commitment of pass 1");
         }
         lap("gadget assembly");
-        std::printf("%llu\n", (unsigned long long)bpg_prover_num_constraints(p));          // prover.rs:89
+        out_constraints = bpg_prover_num_constraints(p);
+        if (!quiet) std::printf("%llu\n", (unsigned long long)out_constraints);          // prover.rs:89
         const uint64_t n = bpg_prover_num_multiplications(p), cap = round_pow2(n);
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         lap("generators");
@@ -398,14 +409,16 @@ struct ProverRun {
         lap("prove (upload + proof)");
         { std::ofstream f(name + ".coms"); for (const std::string &l : coms_lines) f << l; }
         { std::ofstream f(name + ".proof", std::ios::binary); f.write(reinterpret_cast<const char *>(proof.data()), (std::streamsize)plen); }
+        out_proof_len = plen;
         return 0;
     }
-    ~ProverRun() { if (p) bpg_prover_free(p); if (tr) bpg_transcript_free(tr); if (ctx) bpg_ctx_destroy(ctx); }
+    ~ProverRun() { if (p) bpg_prover_free(p); if (tr) bpg_transcript_free(tr); if (ctx && own_ctx) bpg_ctx_destroy(ctx); }
 };
 
 // ================================================================================================ verifier (verifier.rs:46-101)
 struct VerifierRun {
     std::string name; bpg_ctx *ctx = nullptr; bpg_transcript *tr = nullptr; bpg_verifier *v = nullptr;
+    bool own_ctx = true, quiet = false;
     std::map<std::string, Bytes> instance; std::map<std::string, uint32_t> commitments; std::vector<std::string> lines;
 
     std::vector<uint32_t> all_commitments(const std::string &w) {
@@ -520,18 +533,145 @@ struct VerifierRun {
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         Bytes seed(32); { std::ifstream r("/dev/urandom", std::ios::binary); r.read(reinterpret_cast<char *>(seed.data()), 32); }
         const bpg_status s = bpg_verifier_verify(v, ctx, cap, proof.data(), proof.size(), seed.data(), 0);
-        if (s == BPG_OK) { std::puts("true"); return 0; }                 // verifier.rs:91-100
-        if (s == BPG_ERR_VERIFICATION || s == BPG_ERR_FORMAT) { std::puts("false"); return 1; }
+        if (s == BPG_OK) { if (!quiet) std::puts("true"); return 0; }                 // verifier.rs:91-100
+        if (s == BPG_ERR_VERIFICATION || s == BPG_ERR_FORMAT) { if (!quiet) std::puts("false"); return 1; }
         fail(std::string("Verifier::verify: ") + (bpg_last_error() ? bpg_last_error() : "error"));
     }
-    ~VerifierRun() { if (v) bpg_verifier_free(v); if (tr) bpg_transcript_free(tr); if (ctx) bpg_ctx_destroy(ctx); }
+    ~VerifierRun() { if (v) bpg_verifier_free(v); if (tr) bpg_transcript_free(tr); if (ctx && own_ctx) bpg_ctx_destroy(ctx); }
 };
+
+// ================================================================================================ batches
+std::vector<std::string> read_batch(const std::string &path) {
+    std::ifstream f(path);
+    if (!f) fail("cannot open " + path);
+    std::vector<std::string> out; std::string line;
+    while (std::getline(f, line)) {
+        size_t a = line.find_first_not_of(" \t\r"), b = line.find_last_not_of(" \t\r");
+        if (a == std::string::npos || line[a] == '#') continue;
+        out.push_back(line.substr(a, b - a + 1));
+    }
+    return out;
+}
+// one rank of a batch: stems rank, rank + world, ... on ONE context of device `rank mod devices`; a result line per stem on `out`:
+// "<index>\t<constraints>\t<proof bytes>" (prover) or "<index>\t<true|false>" (verifier)
+int run_batch_rank(const std::string &mode, const std::vector<std::string> &stems, uint32_t rank, uint32_t world, FILE *out) {
+    const int32_t ndev = bpg_device_count();
+    if (ndev <= 0) fail("no AMD GPU visible: the library has no CPU path");
+    bpg_ctx *ctx = nullptr;
+    chk(bpg_ctx_create((int32_t)(rank % (uint32_t)ndev), &ctx), "bpg_ctx_create");
+    int rc = 0;
+    try {
+        for (size_t i = rank; i < stems.size(); i += world) {
+            if (mode == "prover") {
+                ProverRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
+                r.run();
+                std::fprintf(out, "%zu\t%llu\t%llu\n", i, (unsigned long long)r.out_constraints, (unsigned long long)r.out_proof_len);
+            } else {
+                VerifierRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
+                const int ok = r.run();
+                if (ok != 0) rc = 1;
+                std::fprintf(out, "%zu\t%s\n", i, ok == 0 ? "true" : "false");
+            }
+            std::fflush(out);
+        }
+    } catch (...) { bpg_ctx_destroy(ctx); throw; }
+    bpg_ctx_destroy(ctx);
+    return rc;
+}
+// the batch command: with one GPU it is the rank; with --gpus N it starts N ranks of this executable (nothing here has touched the GPU), reads their
+// result lines from pipes and prints the summary in file order.  Exit code: 0, 1 when a proof was rejected, 101 when a rank failed (the reference panics).
+int run_batch(const std::string &self_path, const std::string &mode, const std::string &file, uint32_t gpus) {
+    const std::vector<std::string> stems = read_batch(file);
+    std::vector<std::string> result(stems.size());
+    int rc = 0;
+    auto take = [&](const std::string &line) {
+        const size_t tab = line.find('\t');
+        if (tab == std::string::npos) return;
+        const size_t idx = std::stoul(line.substr(0, tab));
+        if (idx < result.size()) result[idx] = line.substr(tab + 1);
+    };
+    if (gpus <= 1) {
+        char *buf = nullptr; size_t len = 0;
+        FILE *mem = open_memstream(&buf, &len);
+        if (!mem) fail("open_memstream");
+        try { rc = run_batch_rank(mode, stems, 0, 1, mem); } catch (...) { std::fclose(mem); std::free(buf); throw; }
+        std::fclose(mem);
+        std::istringstream is(std::string(buf, len)); std::free(buf);
+        for (std::string l; std::getline(is, l);) take(l);
+    } else {
+        struct Child { pid_t pid; int fd; };
+        std::vector<Child> kids;
+        for (uint32_t r = 0; r < gpus; r++) {
+            int pfd[2];
+            if (pipe(pfd) != 0) fail("pipe");
+            const pid_t pid = fork();
+            if (pid < 0) fail("fork");
+            if (pid == 0) {                                  // the rank: a fresh image of this executable with its results on the pipe
+                close(pfd[0]);
+                dup2(pfd[1], 3); if (pfd[1] != 3) close(pfd[1]);
+                const std::string rs = std::to_string(r), ws = std::to_string(gpus);
+                const char *args[] = {self_path.c_str(), mode.c_str(), "--batch", file.c_str(), "--rank", rs.c_str(), "--world", ws.c_str(), nullptr};
+                execv(self_path.c_str(), const_cast<char *const *>(args));
+                std::perror("execv"); _exit(127);
+            }
+            close(pfd[1]);
+            kids.push_back(Child{pid, pfd[0]});
+        }
+        for (Child &k : kids) {
+            std::string all; char buf[4096]; ssize_t n;
+            while ((n = read(k.fd, buf, sizeof buf)) > 0) all.append(buf, (size_t)n);
+            close(k.fd);
+            int st = 0; waitpid(k.pid, &st, 0);
+            const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 101;
+            if (code == 1 && rc == 0) rc = 1; else if (code != 0 && code != 1) rc = 101;
+            std::istringstream is(all);
+            for (std::string l; std::getline(is, l);) take(l);
+        }
+    }
+    for (size_t i = 0; i < stems.size(); i++) {
+        if (result[i].empty()) { std::printf("%s: FAILED\n", stems[i].c_str()); if (rc == 0) rc = 101; continue; }
+        if (mode == "prover") {
+            const size_t tab = result[i].find('\t');
+            std::printf("%s: %s constraints, %s-byte proof\n", stems[i].c_str(), result[i].substr(0, tab).c_str(), result[i].substr(tab + 1).c_str());
+        } else std::printf("%s: %s\n", stems[i].c_str(), result[i].c_str());
+    }
+    return rc;
+}
 
 }  // namespace
 
 int main(int argc, char **argv) {
     std::string self = argv[0]; size_t slash = self.rfind('/'); if (slash != std::string::npos) self = self.substr(slash + 1);
     std::string mode, name;
+    {   // --batch FILE [--gpus N]   (and, for the ranks the command starts itself: --rank R --world N, results on descriptor 3)
+        std::vector<std::string> a(argv + 1, argv + argc);
+        std::string bmode = self.find("verifier") != std::string::npos ? "verifier" : "prover";
+        if (!a.empty() && (a[0] == "prover" || a[0] == "verifier")) { bmode = a[0]; a.erase(a.begin()); }
+        if (a.size() >= 2 && a[0] == "--batch") {
+            try {
+                uint32_t gpus = 1, rank = 0, world = 0;
+                for (size_t k = 2; k + 1 < a.size(); k += 2) {
+                    if (a[k] == "--gpus") gpus = (uint32_t)std::stoul(a[k + 1]);
+                    else if (a[k] == "--rank") rank = (uint32_t)std::stoul(a[k + 1]);
+                    else if (a[k] == "--world") world = (uint32_t)std::stoul(a[k + 1]);
+                    else { std::fprintf(stderr, "unknown option %s\n", a[k].c_str()); return 2; }
+                }
+                if (world) {
+                    FILE *out = fdopen(3, "w");
+                    if (!out) { std::fprintf(stderr, "rank %u: no result pipe\n", rank); return 101; }
+                    const int rc = run_batch_rank(bmode, read_batch(a[1]), rank, world, out);
+                    std::fclose(out);
+                    return rc;
+                }
+                if (gpus < 1 || gpus > 64) { std::fprintf(stderr, "--gpus 1..64\n"); return 2; }
+                char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
+                return run_batch(n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]), bmode, a[1], gpus);
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "%s --batch: %s\n", bmode.c_str(), e.what());
+                return 101;
+            }
+        }
+    }
     if (argc == 3 && (std::string(argv[1]) == "prover" || std::string(argv[1]) == "verifier")) { mode = argv[1]; name = argv[2]; }
     else if (argc == 2 && self.find("verifier") != std::string::npos) { mode = "verifier"; name = argv[1]; }
     else if (argc == 2 && self.find("prover") != std::string::npos) { mode = "prover"; name = argv[1]; }

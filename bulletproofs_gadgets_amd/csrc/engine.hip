@@ -603,6 +603,7 @@ Engine::~Engine() {
     delete impl_;
 }
 
+int Engine::device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 void Engine::profile_set(int mode) { HIPCHK(hipSetDevice(device_)); impl_->prof_reset(); impl_->prof_mode = mode; }
 std::string Engine::profile_report() {
     HIPCHK(hipSetDevice(device_));

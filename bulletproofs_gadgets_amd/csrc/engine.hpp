@@ -54,6 +54,7 @@ public:
     Engine &operator=(const Engine &) = delete;
 
     int device() const { return device_; }
+    static int device_count();      // AMD GPUs visible to the process (0 when there is none)
     // BulletproofGens::new(capacity, 1): derive (or extend) the G/H tables in HBM; capacity must be a power of two
     void gens_ensure(uint64_t capacity);
     uint64_t gens_capacity() const { return gens_cap_; }

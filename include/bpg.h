@@ -98,6 +98,7 @@ typedef struct {
                                     decides) - for hosts that run many proving threads beside their chain threads; 0 spin; -1 = BPG_SYNC_BLOCKING, else 0 */
     const char *gens_cache_dir;  /* directory of the on-disk generator cache (BPG_GENS_CACHE_DIR); NULL = no cache */
 } bpg_config;
+int32_t bpg_device_count(void);          /* AMD GPUs visible to the process (0: none - every bpg_ctx_create then fails with BPG_ERR_DEVICE) */
 bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out);
 bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config /* NULL = defaults */, bpg_ctx **out);
 void bpg_ctx_destroy(bpg_ctx *ctx);
