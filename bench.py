@@ -333,7 +333,7 @@ def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
 # ------------------------------------------------------------------------------------------------ one rank
 def run_rank(args):
     # the throughput leg runs a dozen engine streams: 8 hardware queues instead of the runtime's default 4 measured 8 % more proofs/s
-    # (tools/diag/exp1.sh); read by the HIP runtime at initialisation, so set before torch / the library load it
+    # (measured in round 2); read by the HIP runtime at initialisation, so set before torch / the library load it
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     # every context of this benchmark is created with bpg_ctx_create_ex (ENGINE below): the SERVING profile (a long-lived prover: 51.5 GB of fold
     # tables per device, built once) and blocking stream waits - proving threads sleep instead of spinning; with a dozen of them beside a dozen
@@ -736,6 +736,7 @@ def run_rank(args):
                 "alg_bytes_per_launch": k["alg_bytes"] / launches, "achieved": k["alg_bytes"] / secs / 1e9 if secs > 0 else 0.0,
                 "frac": k["alg_bytes"] / secs / 8e12 if secs > 0 else 0.0,
                 "traffic": t["hbm_bytes_per_launch"] if t else None,
+                "traffic_useful_fetch": t.get("useful_fetch_bytes_per_launch") if t else None,
                 "device_GBps": k["device_bytes"] / secs / 1e9 if secs > 0 else 0.0,
                 "valu": {"unit": "field-mult/s", "achieved": k["field_mults"] / secs if secs > 0 else 0.0, "peak": peak_fm,
                          "frac": (k["field_mults"] / secs / peak_fm) if secs > 0 and peak_fm > 0 else 0.0,
@@ -853,6 +854,21 @@ def run_rank(args):
                            "frac": fm_per_proof * 1e3 / thr["ms_per_proof"] / peak_fm if peak_fm else None,
                            "counted": "field multiplications of the bucket sweeps and the generator folds only (%.3g per proof)" % fm_per_proof}
             thr["hbm"] = {"achieved": b_alg * 1e3 / thr["ms_per_proof"] / 1e9, "unit": "GB/s", "frac": b_alg * 1e3 / thr["ms_per_proof"] / 8e12}
+            # counter evidence for the concurrent mix: two rocprofv3 --pmc passes of `bench.py --in-flight-only` (tools/profile_round.sh pmcthr), quoted only
+            # when they were taken from these sources
+            tthr = ROOT / "profiles" / "pmc_traffic_throughput.json"
+            if tthr.exists():
+                try:
+                    meta = json.loads(tthr.read_text()).get("_meta", {})
+                    if meta.get("source_hash") == src and meta.get("hbm_bytes_per_proof"):
+                        thr["hbm"]["traffic_bytes_per_proof"] = meta["hbm_bytes_per_proof"]
+                        thr["hbm"]["traffic_GBps"] = meta["hbm_bytes_per_proof"] * 1e3 / thr["ms_per_proof"] / 1e9
+                        thr["hbm"]["traffic_frac_of_8TBps"] = meta["hbm_bytes_per_proof"] * 1e3 / thr["ms_per_proof"] / 8e12
+                        thr["hbm"]["traffic_source"] = "profiles/pmc_traffic_throughput.json: FETCH_SIZE x 2 + WRITE_SIZE over %d proofs of the concurrent mix" % meta.get("proofs_profiled", 0)
+                    else:
+                        thr["hbm"]["traffic_source"] = "profiles/pmc_traffic_throughput.json was taken from other sources: not quoted"
+                except Exception as e:      # noqa: BLE001
+                    thr["hbm"]["traffic_source"] = "profiles/pmc_traffic_throughput.json unreadable: %r" % (e,)
             out["throughput"] = thr
         except Exception as e:      # noqa: BLE001 - a failed secondary measurement must not lose the headline
             out["throughput"] = {"error": repr(e)}

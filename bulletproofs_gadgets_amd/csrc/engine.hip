@@ -16,6 +16,9 @@
 #include <mutex>
 #include <thread>
 #include <sched.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "engine.hpp"
 #include "host/fe51.hpp"
 #include "hip/kernels.cuh"
@@ -147,7 +150,10 @@ uint32_t ceil_log2(uint64_t x) { uint32_t l = 0; while ((1ULL << l) < x) l++; re
 
 // On-disk cache of the generator tables (reference src/bin/prover.rs:92 re-derives them on every run).  Opt-in:
 // BPG_GENS_CACHE_DIR names a directory; the file gens_<capacity>.bpg holds a header and the affine Niels table [G | H] exactly as it lives
-// in HBM.  A file is used only if its header, length and checksum agree AND a sample of its points equals freshly derived ones.
+// in HBM.  A file is used only if its header, length and checksum agree AND a sample of its points equals freshly derived ones.  The checksum
+// catches corruption, not an adversary: whoever can write the file chooses the generators (a table with known discrete-log relations lets
+// verify() accept forged proofs), so the cache trusts the FILE SYSTEM: directory and file must belong to the calling user and be writable by
+// nobody else (gens_cache_trusted), files are written through an O_EXCL | O_NOFOLLOW temporary and renamed.
 struct GensCacheHeader { char magic[8]; uint64_t version, capacity, bytes, checksum; };
 static const char kGensMagic[8] = {'B', 'P', 'G', 'G', 'E', 'N', 'S', '1'};
 uint64_t gens_checksum(const uint8_t *p, size_t n) {            // four interleaved multiply-rotate lanes over 8-byte words (about 10 GB/s): corruption, not adversaries
@@ -156,6 +162,13 @@ uint64_t gens_checksum(const uint8_t *p, size_t n) {            // four interlea
     for (; i + 32 <= n; i += 32) for (int k = 0; k < 4; k++) { uint64_t w; std::memcpy(&w, p + i + 8 * k, 8); h[k] = (h[k] ^ w) * 0x100000001b3ull; h[k] = (h[k] << 29) | (h[k] >> 35); }
     for (; i < n; i++) h[0] = (h[0] ^ p[i]) * 0x100000001b3ull;
     return h[0] ^ (h[1] * 3) ^ (h[2] * 5) ^ (h[3] * 7) ^ (uint64_t)n;
+}
+// the cache directory (and, when it exists, the file) is owned by this user and not writable by group or others
+bool gens_cache_trusted(const std::string &dir, const std::string &file) {
+    struct stat st;
+    if (::stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != ::geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;
+    if (::lstat(file.c_str(), &st) != 0) return true;                       // nothing there yet
+    return S_ISREG(st.st_mode) && st.st_uid == ::geteuid() && !(st.st_mode & (S_IWGRP | S_IWOTH));
 }
 std::string gens_cache_path(const std::string &dir, uint64_t cap) {
     if (dir.empty()) return std::string();
@@ -680,7 +693,8 @@ void Engine::gens_ensure(uint64_t capacity) {
         I.adopt(sp); gens_cap_ = cap;
     };
     const std::string cache_file = gens_cache_path(I.gens_cache_dir, cap);
-    if (!cache_file.empty()) { DevBuf loaded; if (I.gens_load_cached(cache_file, cap, loaded)) { publish(loaded); return; } }
+    const bool cache_ok = !cache_file.empty() && gens_cache_trusted(I.gens_cache_dir, cache_file);       // else: derive, never read or write the cache
+    if (cache_ok) { DevBuf loaded; if (I.gens_load_cached(cache_file, cap, loaded)) { publish(loaded); return; } }
     I.h_raw.ensure(2 * cap * 64);
     {   // the two chains are independent XOF streams: squeeze them on two threads; the streams are prefixes of one another across
         // capacities, so a process-wide cache keeps the longest one squeezed so far (contexts of a batch share it)
@@ -715,12 +729,13 @@ void Engine::gens_ensure(uint64_t capacity) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(I.st));
     publish(fresh);
-    if (!cache_file.empty()) I.gens_store_cached(cache_file, cap);
+    if (cache_ok) I.gens_store_cached(cache_file, cap);
 }
 
 bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap, DevBuf &out) {
-    FILE *f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
+    const int fd = ::open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    FILE *f = fd >= 0 ? ::fdopen(fd, "rb") : nullptr;
+    if (!f) { if (fd >= 0) ::close(fd); return false; }
     const size_t bytes = (size_t)2 * cap * sizeof(ge_niels);
     GensCacheHeader hd;
     bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, kGensMagic, 8) == 0 && hd.version == 1 && hd.capacity == cap && hd.bytes == bytes;
@@ -764,9 +779,10 @@ void Engine::Impl::gens_store_cached(const std::string &path, uint64_t cap) {
     HIPCHK(hipMemcpyAsync(host.data(), gens.p, bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     GensCacheHeader hd; std::memcpy(hd.magic, kGensMagic, 8); hd.version = 1; hd.capacity = cap; hd.bytes = bytes; hd.checksum = gens_checksum(host.data(), bytes);
-    const std::string tmp = path + ".tmp." + std::to_string((unsigned long long)now_ms());
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return;                                             // a cache that cannot be written is not an error
+    std::string tmp = path + ".tmp.XXXXXX";
+    const int fd = ::mkstemp(&tmp[0]);                          // O_CREAT | O_EXCL, mode 0600, never through a symbolic link
+    FILE *f = fd >= 0 ? ::fdopen(fd, "wb") : nullptr;
+    if (!f) { if (fd >= 0) { ::close(fd); std::remove(tmp.c_str()); } return; }      // a cache that cannot be written is not an error
     const bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1 && std::fwrite(host.data(), 1, bytes, f) == bytes;
     if (std::fclose(f) != 0 || !ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
 }

@@ -47,7 +47,7 @@ BPG_HD fe fe_fold512(const uint32_t t[16]) {
 // One asm block per product column: lo += sum x_j * y_j, hi = the carries out of bit 64.  The compiler pads every asm statement
 // that writes an SGPR with an s_nop; a block per column instead of one per limb product leaves 15 of them in a multiplication
 // instead of 64, which is worth +13 % where one wave per SIMD runs a dependent chain (Horner tails, compressions) and nothing at
-// two waves or more (tools/diag/bench_fe.hip).
+// two waves or more (round-1 microbenchmark; the issue costs behind it: tools/diag/bench_issue.hip, profiles/r03_issue_costs.txt).
 #define BPG_MAC(X, Y, HI) "v_mad_u64_u32 %0, %2, %" X ", %" Y ", %0\n\tv_addc_co_u32_e64 %1, %2, 0, " HI ", %2\n\t"
 __device__ __forceinline__ void fe_col1(uint64_t &lo, uint32_t &hi, uint32_t x0, uint32_t y0) {
     uint64_t c; asm(BPG_MAC("3", "4", "0") : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x0), "v"(y0));

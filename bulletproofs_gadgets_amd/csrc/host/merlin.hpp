@@ -182,7 +182,7 @@ __attribute__((target("avx512f,avx512vl"))) static inline void strobe_rng_bulk64
 }
 
 // EIGHT independent sponges at once: the same lanes-in-registers round body on ZMM registers, lane v of every register belonging to
-// sponge v.  On Zen 5 a 512-bit VPTERNLOGQ / VPROLQ issues at the rate of a 128-bit one (tools/diag/zen5_wide.cpp), so eight TranscriptRng
+// sponge v.  On Zen 5 a 512-bit VPTERNLOGQ / VPROLQ issues at the rate of a 128-bit one (profiles/r02_zen5_vector_width.txt), so eight TranscriptRng
 // chains of eight different proofs cost one core about what one chain costs it - the serial chain of ONE proof gets no shorter, a core's
 // chain THROUGHPUT goes up eightfold.  Same bytes per sponge as strobe_rng_bulk64_xmm (tests/test_device_arith_host.py).
 #define KZ_X3(a, b, c) _mm512_ternarylogic_epi64(a, b, c, 0x96)

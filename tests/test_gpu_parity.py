@@ -956,3 +956,18 @@ def test_generator_cache_on_disk(tmp_path, monkeypatch):
         path.write_bytes(bad)
         assert table() == (want, proof)
         assert path.read_bytes() == good                   # the re-derived table replaced the bad file
+    # the cache trusts the file system, so it only touches what belongs to this user alone: a directory or file that others may write,
+    # or a symbolic link in the file's place, is neither read nor written - the table is derived
+    import os, stat
+    assert stat.S_IMODE(path.stat().st_mode) & 0o022 == 0 and not list(tmp_path.glob("*.tmp.*"))
+    os.chmod(path, 0o666)
+    path.write_bytes(bytes(swapped))                       # would be refused by the sample check anyway; must not even be replaced now
+    assert table() == (want, proof) and path.read_bytes() == bytes(swapped)
+    os.chmod(path, 0o600); path.write_bytes(good)
+    os.chmod(tmp_path, 0o777)
+    path.unlink()
+    assert table() == (want, proof) and not path.exists()  # a directory others can write: no cache file appears
+    os.chmod(tmp_path, 0o700)
+    real = tmp_path / "elsewhere.bin"; real.write_bytes(good)
+    path.symlink_to(real)
+    assert table() == (want, proof) and path.is_symlink() and real.read_bytes() == good

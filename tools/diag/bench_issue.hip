@@ -12,7 +12,7 @@ template <int V> __global__ void __launch_bounds__(256) kb(uint32_t *out, uint32
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t a = t * 2654435761u + 1, b = t ^ 0x9e3779b9u, c = t + 77, d = ~t;
-    uint64_t p = t, q = t + 1, r = t + 2, s = t + 3, cc;
+    uint64_t p = t, q = t + 1, r = t + 2, s = t + 3, cc; uint32_t c2 = t, e0 = t * 3, e1 = t * 5;
     for (uint32_t i = 0; i < iters; i++) {
         if (V == 0) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_mad_u64_u32 %1, %4, %6, %7, %1\n\tv_mad_u64_u32 %2, %4, %7, %8, %2\n\tv_mad_u64_u32 %3, %4, %8, %5, %3"
                                           : "+v"(p), "+v"(q), "+v"(r), "+v"(s), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }                  // 4 independent accumulators
@@ -36,6 +36,23 @@ template <int V> __global__ void __launch_bounds__(256) kb(uint32_t *out, uint32
                                           : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"((uint32_t)p), "v"((uint32_t)q), "v"((uint32_t)r), "v"((uint32_t)s));) }
         if (V == 10) { REP16(asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
                                            : "+v"(p), "+v"(a), "=&s"(cc) : "v"(b), "v"(c), "v"(d));) }                                          // the product's column pattern: 2 MAD + 2 carry
+        if (V == 15) { REP16(asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2\n\ts_nop 0"
+                                           : "+v"(p), "+v"(a), "=&s"(cc) : "v"(b), "v"(c), "v"(d));) }                                          // the same with one s_nop per four instructions (counted as 4)
+        if (V == 16) { REP16(asm volatile("v_mad_u64_u32 %0, %2, %4, %5, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2\n\tv_mov_b32 %3, %1"
+                                           : "+v"(p), "+v"(a), "=&s"(cc), "+v"(c2) : "v"(b), "v"(c), "v"(d));) }                                  // the same with one v_mov per four instructions (counted as 4)
+        // a radix-2^29 column: k MADs on one accumulator, then limb = lo & M29, carry = {hi >> 29 : alignbit(hi, lo, 29)} (counted as 4 "instructions" per group so that the
+        // printed figure x 4 = ns per column)
+        if (V == 17) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %0, %4, %7, %8, %0\n\tv_mad_u64_u32 %0, %4, %8, %5, %0\n\tv_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+                                           "v_and_b32 %1, 0x1fffffff, %2\n\tv_alignbit_b32 %2, %3, %2, 29\n\tv_lshrrev_b32 %3, 29, %3"
+                                           : "+v"(p), "+v"(c2), "+v"(e0), "+v"(e1), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }      // 5 MADs + 3 plain
+        if (V == 18) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_mad_u64_u32 %0, %4, %7, %8, %0\n\tv_mad_u64_u32 %0, %4, %8, %5, %0\n\tv_mad_u64_u32 %0, %4, %5, %7, %0\n\t"
+                                           "v_mad_u64_u32 %0, %4, %6, %8, %0\n\tv_mad_u64_u32 %0, %4, %7, %5, %0\n\tv_mad_u64_u32 %0, %4, %8, %6, %0\n\tv_mad_u64_u32 %0, %4, %5, %5, %0\n\t"
+                                           "v_and_b32 %1, 0x1fffffff, %2\n\tv_alignbit_b32 %2, %3, %2, 29\n\tv_lshrrev_b32 %3, 29, %3"
+                                           : "+v"(p), "+v"(c2), "+v"(e0), "+v"(e1), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }      // 9 MADs + 3 plain
+        if (V == 19) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_add_u32 %1, %1, %5\n\tv_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_add_u32 %2, %2, %6\n\tv_mad_u64_u32 %0, %4, %7, %8, %0\n\tv_add_u32 %3, %3, %7\n\tv_mad_u64_u32 %0, %4, %8, %5, %0\n\tv_add_u32 %1, %1, %8"
+                                           : "+v"(p), "+v"(c2), "+v"(e0), "+v"(e1), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }      // MAD, add alternating (8 instr, counted 4)
+        if (V == 20) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_add_u32 %1, %1, %5\n\tv_add_u32 %2, %2, %6\n\tv_mad_u64_u32 %0, %4, %6, %7, %0\n\tv_add_u32 %3, %3, %7\n\tv_add_u32 %1, %1, %8"
+                                           : "+v"(p), "+v"(c2), "+v"(e0), "+v"(e1), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }      // MAD + 2 adds (6 instr, counted 4)
         if (V == 11) { REP16(asm volatile("v_lshl_add_u64 %0, %0, 0, %1\n\tv_lshl_add_u64 %1, %1, 0, %2\n\tv_lshl_add_u64 %2, %2, 0, %3\n\tv_lshl_add_u64 %3, %3, 0, %0"
                                            : "+v"(p), "+v"(q), "+v"(r), "+v"(s));) }
         if (V == 12) { REP16(asm volatile("v_dot2_u32_u16 %0, %4, %5, %0\n\tv_dot2_u32_u16 %1, %5, %6, %1\n\tv_dot2_u32_u16 %2, %6, %7, %2\n\tv_dot2_u32_u16 %3, %7, %4, %3"
@@ -45,7 +62,7 @@ template <int V> __global__ void __launch_bounds__(256) kb(uint32_t *out, uint32
         if (V == 14) { REP16(asm volatile("v_mad_i64_i32 %0, %4, %5, %6, %0\n\tv_mad_i64_i32 %1, %4, %6, %7, %1\n\tv_mad_i64_i32 %2, %4, %7, %8, %2\n\tv_mad_i64_i32 %3, %4, %8, %5, %3"
                                            : "+v"(p), "+v"(q), "+v"(r), "+v"(s), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }
     }
-    out[t] = a + b + c + d + (uint32_t)p + (uint32_t)q + (uint32_t)r + (uint32_t)s + (uint32_t)((p ^ q ^ r ^ s) >> 32);
+    out[t] = c2 + e0 + e1 + a + b + c + d + (uint32_t)p + (uint32_t)q + (uint32_t)r + (uint32_t)s + (uint32_t)((p ^ q ^ r ^ s) >> 32);
 #endif
 }
 
@@ -68,7 +85,13 @@ int main() {
     run<0>(d_out, "v_mad_u64_u32 x4 independent");
     run<1>(d_out, "v_mad_u64_u32 one accumulator");
     run<10>(d_out, "v_mad_u64_u32 + v_addc (column pattern)");
+    run<15>(d_out, "column pattern + s_nop 0 per 4 (time per 4 counted instructions / 4)");
+    run<16>(d_out, "column pattern + v_mov per 4 (time per 4 counted instructions / 4)");
     run<14>(d_out, "v_mad_i64_i32 x4 independent");
+    run<17>(d_out, "radix-2^29 column: 5 MADs + and, alignbit, lshr (x 4 = ns per column)");
+    run<18>(d_out, "radix-2^29 column: 9 MADs + and, alignbit, lshr (x 4 = ns per column)");
+    run<19>(d_out, "4 x (MAD, add) (x 4 = ns per 8 instructions)");
+    run<20>(d_out, "2 x (MAD, add, add) (x 4 = ns per 6 instructions)");
     run<2>(d_out, "v_add_u32");
     run<3>(d_out, "v_addc_co_u32 chain (vcc)");
     run<4>(d_out, "v_alignbit_b32");

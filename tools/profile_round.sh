@@ -6,15 +6,19 @@
 #   stats  rocprofv3 --kernel-trace --stats of bench.py --headline-only (as timed: 14 proving streams), of the same with one stream and
 #          one chain thread (kernels alone on the GPU), and of --in-flight-only  -> gpurun_out/<tag>_stats/, <tag>_stats_single/, <tag>_stats_inflight/
 #   pmc    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only                -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/, <tag>_pmc_traffic.json
+#   pmcthr the same two --pmc passes over `bench.py --in-flight-only` (the concurrent mix of the throughput leg)               -> gpurun_out/<tag>_pmc_traffic_throughput.json
 #   bench  the default bench line exactly as the driver runs it (cpu_baseline, throughput, batch) -> gpurun_out/<tag>_bench_plain.json
 # rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
 set -o pipefail
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 stages=${*:-calib stats pmc bench}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p "$out"
 export TMPDIR=/tmp
+# read by the HIP runtime when it initialises - under rocprofv3 that is BEFORE python starts (the profiler's preloaded library touches the GPU first), so
+# bench.py's os.environ.setdefault would come too late and the profiled runs would use 4 hardware queues where the timed line uses 8
+export GPU_MAX_HW_QUEUES=8
 has() { [[ " $stages " == *" $1 "* ]]; }
 csv() { find "$1" -name "*$2" | head -1; }
 
@@ -40,8 +44,17 @@ if has pmc; then
     echo "fetch done"
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmc_write" -o "$tag" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 1 --warmup 1 > /dev/null 2> "$out/${tag}_pmc_write.err") || { echo "write pass failed"; tail -5 "$out/${tag}_pmc_write.err"; exit 1; }
     echo "write done"
-    calib="$out/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/${tag}_fetch_calibration.json"
+    calib="$out/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/r02_fetch_calibration.json"
     python3 "$root/tools/pmc_summarize.py" "$(csv "$out/${tag}_pmc_fetch" counter_collection.csv)" "$(csv "$out/${tag}_pmc_write" counter_collection.csv)" "$calib" "$out/${tag}_pmc_traffic.json" || exit 1
+fi
+if has pmcthr; then
+    # the same two counters over the CONCURRENT kernel mix of the throughput leg (6 proving streams): what a proof costs in HBM bytes when the GPU is shared
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_pmcthr_fetch" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight-steps 8 > "$out/${tag}_pmcthr_fetch.json" 2> "$out/${tag}_pmcthr_fetch.err") || { echo "throughput fetch pass failed"; tail -5 "$out/${tag}_pmcthr_fetch.err"; exit 1; }
+    echo "throughput fetch done"
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/${tag}_pmcthr_write" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight-steps 8 > "$out/${tag}_pmcthr_write.json" 2> "$out/${tag}_pmcthr_write.err") || { echo "throughput write pass failed"; tail -5 "$out/${tag}_pmcthr_write.err"; exit 1; }
+    echo "throughput write done"
+    calib="$out/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/${tag}_fetch_calibration.json"; [ -f "$calib" ] || calib="$root/profiles/r02_fetch_calibration.json"
+    python3 "$root/tools/pmc_summarize.py" "$(csv "$out/${tag}_pmcthr_fetch" counter_collection.csv)" "$(csv "$out/${tag}_pmcthr_write" counter_collection.csv)" "$calib" "$out/${tag}_pmc_traffic_throughput.json" "$out/${tag}_pmcthr_fetch.json" || exit 1
 fi
 if has bench; then
     timeout -k 10 800 python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_plain.json" 2> "$out/${tag}_bench_plain.err" || { echo "bench failed"; tail -5 "$out/${tag}_bench_plain.err"; exit 1; }
