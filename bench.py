@@ -301,6 +301,40 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
             "rate": "proofs completed after the first %d completions / time from that completion to the last" % skip}
 
 
+def small_configs(bpg, workloads, device):
+    """Secondary: BASELINE.json's small configurations (parity cases, never `value`) - median prove / verify time of a lone proof under the library's
+    default one-shot profile and under the serving profile of this benchmark (8-bit window tables for circuits up to 2^14 multipliers)."""
+    out = {}
+    for prof, kw in (("one_shot", {}), ("serving", dict(ENGINE))):
+        c = bpg.Context(device, **kw)
+        rows = {}
+        try:
+            for name, mk in (("cfg2_bounds_check_64", lambda: workloads.bounds_check_64(c, seed=0)),
+                             ("cfg1_size_merkle8_2^14", lambda: workloads.merkle_full_tree(c, leaves=8, seed=7)),
+                             ("cfg3_mimc_preimage_2^16", lambda: workloads.mimc_preimage(c, nbytes=2130, seed=0, label=b"MiMCHash"))):
+                a = mk(); inst = a.prover.instance(); state = a.transcript.state
+                c.gens_ensure(a.gens_capacity); res = c.upload(inst)
+                for i in range(4):
+                    res.prove(state, inst.v_blinding, bytes(32), 0)
+                ts = []
+                for i in range(7):
+                    t0 = time.perf_counter(); proof, _ = res.prove(state, inst.v_blinding, bytes([i + 1]) * 32, 0); ts.append(time.perf_counter() - t0)
+                tm = res.prove(state, inst.v_blinding, bytes(32), 0, timings=True)[2]
+                coms = b"".join(a.commitments)
+                t0 = time.perf_counter()
+                oks = [res.verify(state, coms, proof) for _ in range(5)]
+                dv = (time.perf_counter() - t0) / 5
+                dt = sorted(ts)[len(ts) // 2]
+                rows[name] = {"n": inst.n, "N": a.gens_capacity, "q": inst.q, "prove_ms": dt * 1e3, "constraints_per_s": inst.q / dt, "host_chain_ms": tm["rng_host"],
+                              "ipa_ms": tm["ipa"], "verify_ms": dv * 1e3, "verified": all(o == 0 for o in oks)}
+                res.free()
+        finally:
+            c.close()
+        out[prof] = rows
+    out["note"] = "one proof at a time, chain drawn inside the call; median of 7; not the headline"
+    return out
+
+
 def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
     """Untimed, secondary: one proof from scratch - 512 commitments, host assembly of the reference's 512-leaf tree, flatten, upload, prove -
     as upstream orders it, and with the TranscriptRng chain started right after the commitments (bpg_prover_start_blinding, include/bpg.h)."""
@@ -879,6 +913,11 @@ def run_rank(args):
             out["end_to_end"] = end_to_end(bpg, workloads, ctx, a.gens_capacity, last[0], seed_for(args.steps - 1))
         except Exception as e:      # noqa: BLE001
             out["end_to_end"] = {"error": repr(e)}
+    if world == 1 and not args.headline_only:
+        try:
+            out["small_configs"] = small_configs(bpg, workloads, device_index)
+        except Exception as e:      # noqa: BLE001
+            out["small_configs"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and not args.headline_only:
         log("cpu_baseline: oracle on %d leaves (about %d s on one core) ..." % (args.baseline_leaves, 150 * args.baseline_leaves // 512 + 2))
         cb = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves, {"leaves": args.leaves, "a": a, "inst": inst, "res": res})
