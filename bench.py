@@ -843,13 +843,22 @@ def run_rank(args):
            "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
                                   % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                       "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
-                      "chain": ("the steps are dealt round-robin to %d proving streams per GPU (engine contexts: own HIP stream and proving thread, generator tables "
-                                "shared); the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) are drawn by %d chain threads, "
-                                "%d per stream, each stream keeping the chain of its next step queued. All %d chains start and end inside the timed region: "
-                                "nothing can finish in its first ~0.3 s, during which the streams run A_I, A_O and most of S under their chains"
-                                % (n_streams, lane_workers * n_streams, lane_workers, args.steps))
+                      "chain": (("the steps are dealt round-robin to %d proving streams per GPU (engine contexts: own HIP stream and proving thread, generator tables "
+                                 "shared); the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) are drawn by ONE pool of %d chain "
+                                 "threads shared by the streams (bpg_chain_pool_create; lanes per thread %s: a thread with one lane draws a chain in 0.30 s, a lockstep "
+                                 "thread its chains in 0.38 s), sized for the %s cores this rank has, so that the first chain of every stream is drawn at once. All %d "
+                                 "chains start and end inside the timed region: nothing can finish in its first ~0.3 s, during which the streams run A_I, A_O and "
+                                 "most of S under their chains" % (n_streams, len(pool_lanes), pool_lanes, placement.get("cores_per_rank"), args.steps))
+                                if pool is not None else
+                                ("the steps are dealt round-robin to %d proving streams per GPU (engine contexts: own HIP stream and proving thread, generator tables "
+                                 "shared); the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) are drawn by %d chain threads, "
+                                 "%d per stream, each stream keeping the chain of its next step queued. All %d chains start and end inside the timed region: "
+                                 "nothing can finish in its first ~0.3 s, during which the streams run A_I, A_O and most of S under their chains"
+                                 % (n_streams, lane_workers * n_streams, lane_workers, args.steps)))
                                if prefetch else "every chain is drawn inside its own prove call",
-                      "host_threads_per_gpu": {"chain_workers": lane_workers * n_streams if prefetch else 0, "proving": n_streams},
+                      "host_threads_per_gpu": {"chain_workers": (len(pool_lanes) if pool is not None else lane_workers * n_streams) if prefetch else 0, "proving": n_streams,
+                                               "chain_pool_lanes": pool_lanes if pool is not None else None,
+                                               "note": "chain threads are busy for the whole chain; proving threads sleep in their stream waits (blocking sync)"},
                       "proving_streams_per_gpu": n_streams,
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
@@ -925,7 +934,7 @@ def run_rank(args):
         # the ratio against the raw port and against a CPU time halved for upstream's avx2_backend (Cargo.toml:20)
         cb["gpu_over_cpu"] = out["value"] / cb["value"]
         cb["gpu_over_cpu_avx2_adjusted"] = out["value"] / (2.0 * cb["value"])
-        cb["gpu_side_host_threads"] = (lane_workers * n_streams if prefetch else 0) + n_streams
+        cb["gpu_side_host_threads"] = ((len(pool_lanes) if pool is not None else lane_workers * n_streams) if prefetch else 0) + n_streams
         if single is not None:
             cb["single_stream_over_cpu"] = single["value"] / cb["value"]      # one GPU + two host threads against one core
         out["cpu_baseline"] = cb
