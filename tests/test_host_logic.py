@@ -350,3 +350,39 @@ def test_host_thread_planning_on_synthetic_topologies():
             lanes = bench.plan_chain_pool(cores, n)
             assert lanes and all(1 <= x <= 8 for x in lanes) and len(lanes) <= max(1, cores - 2) and sum(lanes) <= n
             assert sum(lanes) == n or sum(lanes) >= 8 * max(1, cores - 2) - 7      # short only when the cores cannot carry n chains at all
+
+
+def test_config_struct_matches_the_header_and_pool_api_without_a_gpu(tmp_path):
+    """bpg_config as the Python binding lays it out == as a C compiler lays out include/bpg.h (size and every offset); the chain pool and the
+    device count are usable without a device (threads idle, count 0), bad arguments are refused."""
+    import ctypes as C
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bpg.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bpg_config), '
+                   'offsetof(bpg_config, struct_size), offsetof(bpg_config, profile), offsetof(bpg_config, table_budget_gb), offsetof(bpg_config, chain_workers), '
+                   'offsetof(bpg_config, chain_lanes), offsetof(bpg_config, blocking_sync), offsetof(bpg_config, gens_cache_dir)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", str(O.ROOT / "include"), "-o", str(exe), str(src)])
+    want = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    got = [C.sizeof(bpg.Config)] + [getattr(bpg.Config, f).offset for f, _ in bpg.Config._fields_]
+    assert got == want, (got, want)
+    cfg = bpg.make_config("serving", table_budget_gb=12.5, chain_workers=3, chain_lanes=4, blocking_sync=True, gens_cache_dir="/tmp/x")
+    assert (cfg.struct_size, cfg.profile, cfg.table_budget_gb, cfg.chain_workers, cfg.chain_lanes, cfg.blocking_sync, cfg.gens_cache_dir) == \
+        (want[0], 2, 12.5, 3, 4, 1, b"/tmp/x")
+    lib = bpg.lib()
+    lib.bpg_device_count.restype = C.c_int32
+    import torch
+    assert lib.bpg_device_count() == torch.cuda.device_count()
+    pool = bpg.ChainPool([1, 1, 8])                          # three idle threads
+    assert pool.capacity == 10
+    pool.close()
+    for bad in ([], [0], [9], [1] * 257):
+        with pytest.raises(bpg.BpgError):
+            bpg.ChainPool(bad)
+    if not torch.cuda.is_available():
+        with pytest.raises(bpg.BpgError) as e:
+            bpg.Context(0, profile="serving", table_budget_gb=1.0)
+        assert e.value.status == 7                          # no device: DEVICE_ERROR, also through bpg_ctx_create_ex
+    with pytest.raises(bpg.BpgError) as e:
+        bpg.Context(0, profile=2, chain_lanes=9)
+    assert e.value.status in (4, 7)
