@@ -296,9 +296,10 @@ def test_python_binding_checks_buffer_lengths_and_defaults_to_fresh_seeds():
 
 
 def test_profile_tooling_on_synthetic_counter_files(tmp_path):
-    """tools/calib/fetch_factor.py and tools/pmc_summarize.py on hand-made rocprofv3 CSVs: the FETCH_SIZE factor is known bytes / counter bytes,
-    gather kernels get the calibrated factor, everything else the streaming one, and the result carries the hash of the kernel sources
-    (bench.py quotes `traffic` only when that hash is the one of the sources it runs)."""
+    """tools/calib/fetch_factor.py and tools/pmc_summarize.py on hand-made rocprofv3 CSVs: the FETCH_SIZE factor is known bytes / counter bytes;
+    HBM bytes are FETCH_SIZE x 2 + WRITE_SIZE for EVERY kernel, gather kernels carry the calibrated useful-bytes figure in a field of its own, and
+    the result carries the hash of the kernel sources (bench.py quotes `traffic` only when that hash is the one of the sources it runs); with the
+    JSON line of a profiled --in-flight-only run the summary also gives the bytes per proof of the concurrent mix."""
     import json, subprocess, sys
     root = pathlib.Path(__file__).resolve().parent.parent
     known = {"table_bytes": 1000, "rows_gathered": 10, "known_bytes": {"k_calib_stream": 2048.0, "k_calib_gather<6>": 960.0, "k_calib_gather<8>": 960.0},
@@ -320,9 +321,16 @@ def test_profile_tooling_on_synthetic_counter_files(tmp_path):
     import bench
     assert t["_meta"]["source_hash"] == bench.source_hash() and len(t["_meta"]["source_hash"]) == 16
     sweep, poly = t["k_bucket_chunks"], t["k_poly_t"]
-    assert sweep["launches"] == 2 and sweep["fetch_factor"] == 960.0 / 1024.0 and poly["fetch_factor"] == 2.0
-    assert abs(sweep["hbm_bytes_per_launch"] - (200 * 1024 * 960.0 / 1024.0 + 4 * 1024)) < 1e-6
+    assert sweep["launches"] == 2 and sweep["access"] == "gather" and poly["access"] == "stream" and "useful_fetch_bytes_per_launch" not in poly
+    assert abs(sweep["hbm_bytes_per_launch"] - (200 * 1024 * 2.0 + 4 * 1024)) < 1e-6                 # raw counter x 2, never the calibrated factor
+    assert abs(sweep["useful_fetch_bytes_per_launch"] - 200 * 1024 * 960.0 / 1024.0) < 1e-6
     assert abs(poly["hbm_bytes_per_launch"] - (10 * 1024 * 2.0 + 2 * 1024)) < 1e-6
+    assert "k_fold_points_wnaf" in t["_meta"]["gather_kernels"] and "k_tt_round8" in t["_meta"]["gather_kernels"]
+    (tmp_path / "line.json").write_text("noise\n" + json.dumps({"in_flight": {"proofs": 48, "proofs_in_flight": 6}}) + "\n")
+    subprocess.check_call([sys.executable, str(root / "tools/pmc_summarize.py"), str(tmp_path / "fetch.csv"), str(tmp_path / "write.csv"), str(tmp_path / "calib.json"),
+                           str(tmp_path / "thr.json"), str(tmp_path / "line.json")], stdout=subprocess.DEVNULL)
+    m = json.loads((tmp_path / "thr.json").read_text())["_meta"]
+    assert m["proofs_profiled"] == 48 + 6 + 1 and abs(m["hbm_bytes_per_proof"] - (2 * (200 * 1024 * 2 + 4 * 1024) + 10 * 1024 * 2 + 2 * 1024) / 55.0) < 1e-6
     assert bench._cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
 
 
