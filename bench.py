@@ -785,8 +785,10 @@ def run_rank(args):
     if ranked:
         dom = kernel_roofline(ranked[0])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
-                    "frac": dom["frac"], "traffic": dom["traffic"], "traffic_source": traffic_note, "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "frac": dom["frac"], "traffic": dom["traffic"], "traffic_useful_fetch": dom["traffic_useful_fetch"], "traffic_source": traffic_note, "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
                     "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                    "traffic_definition": "HBM-side bytes per launch from the PMC counters: FETCH_SIZE x 2 (gfx950 tallies 64 B per 128-byte request) + WRITE_SIZE; "
+                                          "traffic_useful_fetch = FETCH_SIZE x the factor calibrated on random 96-byte rows (the bytes the kernel asked for, not HBM traffic)",
                     "alg_bytes_definition": "information content, SURVEY.md 8(d): S + P = 64 B per MSM term for the bucket sweep (once per term, not per window); "
                                             "32 B per point read or written for a generator fold",
                     "device_GBps": dom["device_GBps"],
