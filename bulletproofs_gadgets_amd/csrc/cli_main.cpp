@@ -4,11 +4,13 @@
 //     bpg_prover   NAME    reads NAME.gadgets / NAME.inst / NAME.wtns, writes NAME.coms / NAME.proof, prints #constraints
 //     bpg_verifier NAME    reads NAME.gadgets / NAME.inst / NAME.coms / NAME.proof, prints true|false, exit code 0|1
 //
-//     bpg_prover | bpg_verifier --batch FILE [--gpus N]
+//     bpg_prover | bpg_verifier --batch FILE [--gpus N] [--workers W]
 //                          FILE lists one NAME per line - a batch of independent proofs (the reference's own batch is its CI workflow, prover then
 //                          verifier over twelve stems: .github/workflows/integration_tests.yml:19-58).  One process per GPU (the command starts them
-//                          itself, before it touches the GPU); rank r takes stems r, r + N, ... with ONE engine context, writes their files and
-//                          reports to the parent, which prints one summary line per stem in file order.  Same files as N = 1 and as one run per stem.
+//                          itself, before it touches the GPU); rank r takes stems r, r + N, ..., deals them to W host threads (default 4) with an
+//                          engine context each - a proof is 0.5 s of host work (parsing, assembly, blinding chain) and 30 ms of GPU - writes their
+//                          files and reports to the parent, which prints one summary line per stem in file order.  Same files as N = 1, as W = 1
+//                          and as one run per stem.
 //
 // One executable, dispatched on argv[0] (or on a first argument "prover" / "verifier").  Grammar: the seven gadget lines of
 // src/lalrpop/gadget_grammar.lalrpop:6-85 plus OR [ { .. } { .. } ] blocks (prover.rs:202-238, verifier.rs:162-186).
@@ -27,6 +29,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include <sys/wait.h>
 #include <unistd.h>
 #include "../../include/bpg.h"
@@ -552,35 +557,60 @@ std::vector<std::string> read_batch(const std::string &path) {
     }
     return out;
 }
-// one rank of a batch: stems rank, rank + world, ... on ONE context of device `rank mod devices`; a result line per stem on `out`:
+// one rank of a batch: stems rank, rank + world, ... on device `rank mod devices`, dealt to `workers` host threads with an engine context each (the
+// contexts of a process share the generator tables of the device).  One proof keeps a host thread busy for its parsing, assembly and blinding chain
+// (0.5 s at 2^20) and the GPU for 30 ms, so a few workers per GPU multiply the rate of a batch; every stem is still proved exactly as a lone
+// `bpg_prover NAME` run would prove it (own transcript, own blinding stream).  A result line per stem on `out`:
 // "<index>\t<constraints>\t<proof bytes>" (prover) or "<index>\t<true|false>" (verifier)
-int run_batch_rank(const std::string &mode, const std::vector<std::string> &stems, uint32_t rank, uint32_t world, FILE *out) {
+int run_batch_rank(const std::string &mode, const std::vector<std::string> &stems, uint32_t rank, uint32_t world, uint32_t workers, FILE *out) {
     const int32_t ndev = bpg_device_count();
     if (ndev <= 0) fail("no AMD GPU visible: the library has no CPU path");
-    bpg_ctx *ctx = nullptr;
-    chk(bpg_ctx_create((int32_t)(rank % (uint32_t)ndev), &ctx), "bpg_ctx_create");
-    int rc = 0;
-    try {
-        for (size_t i = rank; i < stems.size(); i += world) {
-            if (mode == "prover") {
-                ProverRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
-                r.run();
-                std::fprintf(out, "%zu\t%llu\t%llu\n", i, (unsigned long long)r.out_constraints, (unsigned long long)r.out_proof_len);
-            } else {
-                VerifierRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
-                const int ok = r.run();
-                if (ok != 0) rc = 1;
-                std::fprintf(out, "%zu\t%s\n", i, ok == 0 ? "true" : "false");
+    std::vector<size_t> mine;
+    for (size_t i = rank; i < stems.size(); i += world) mine.push_back(i);
+    if (workers < 1) workers = 1;
+    if (workers > mine.size()) workers = (uint32_t)std::max<size_t>(mine.size(), 1);
+    std::atomic<size_t> next(0);
+    std::atomic<int> rc(0);
+    std::mutex out_mu; std::string first_error;
+    auto work = [&]() {
+        bpg_ctx *ctx = nullptr;
+        try {
+            chk(bpg_ctx_create((int32_t)(rank % (uint32_t)ndev), &ctx), "bpg_ctx_create");
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= mine.size()) break;
+                const size_t i = mine[k];
+                char line[128];
+                if (mode == "prover") {
+                    ProverRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
+                    r.run();
+                    std::snprintf(line, sizeof line, "%zu\t%llu\t%llu\n", i, (unsigned long long)r.out_constraints, (unsigned long long)r.out_proof_len);
+                } else {
+                    VerifierRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
+                    const int ok = r.run();
+                    if (ok != 0) { int want = 0; rc.compare_exchange_strong(want, 1); }
+                    std::snprintf(line, sizeof line, "%zu\t%s\n", i, ok == 0 ? "true" : "false");
+                }
+                std::lock_guard<std::mutex> lk(out_mu);
+                std::fputs(line, out); std::fflush(out);
             }
-            std::fflush(out);
+        } catch (const std::exception &e) {                  // this worker stops; its unfinished stem is reported as FAILED by the parent
+            std::lock_guard<std::mutex> lk(out_mu);
+            if (first_error.empty()) first_error = e.what();
+            rc.store(101);
         }
-    } catch (...) { bpg_ctx_destroy(ctx); throw; }
-    bpg_ctx_destroy(ctx);
-    return rc;
+        if (ctx) bpg_ctx_destroy(ctx);
+    };
+    std::vector<std::thread> th;
+    for (uint32_t w = 1; w < workers; w++) th.emplace_back(work);
+    work();
+    for (std::thread &t : th) t.join();
+    if (!first_error.empty()) std::fprintf(stderr, "%s --batch (rank %u): %s\n", mode.c_str(), rank, first_error.c_str());
+    return rc.load();
 }
 // the batch command: with one GPU it is the rank; with --gpus N it starts N ranks of this executable (nothing here has touched the GPU), reads their
 // result lines from pipes and prints the summary in file order.  Exit code: 0, 1 when a proof was rejected, 101 when a rank failed (the reference panics).
-int run_batch(const std::string &self_path, const std::string &mode, const std::string &file, uint32_t gpus) {
+int run_batch(const std::string &self_path, const std::string &mode, const std::string &file, uint32_t gpus, uint32_t workers) {
     const std::vector<std::string> stems = read_batch(file);
     std::vector<std::string> result(stems.size());
     int rc = 0;
@@ -594,7 +624,7 @@ int run_batch(const std::string &self_path, const std::string &mode, const std::
         char *buf = nullptr; size_t len = 0;
         FILE *mem = open_memstream(&buf, &len);
         if (!mem) fail("open_memstream");
-        try { rc = run_batch_rank(mode, stems, 0, 1, mem); } catch (...) { std::fclose(mem); std::free(buf); throw; }
+        try { rc = run_batch_rank(mode, stems, 0, 1, workers, mem); } catch (...) { std::fclose(mem); std::free(buf); throw; }
         std::fclose(mem);
         std::istringstream is(std::string(buf, len)); std::free(buf);
         for (std::string l; std::getline(is, l);) take(l);
@@ -609,8 +639,8 @@ int run_batch(const std::string &self_path, const std::string &mode, const std::
             if (pid == 0) {                                  // the rank: a fresh image of this executable with its results on the pipe
                 close(pfd[0]);
                 dup2(pfd[1], 3); if (pfd[1] != 3) close(pfd[1]);
-                const std::string rs = std::to_string(r), ws = std::to_string(gpus);
-                const char *args[] = {self_path.c_str(), mode.c_str(), "--batch", file.c_str(), "--rank", rs.c_str(), "--world", ws.c_str(), nullptr};
+                const std::string rs = std::to_string(r), ws = std::to_string(gpus), ks = std::to_string(workers);
+                const char *args[] = {self_path.c_str(), mode.c_str(), "--batch", file.c_str(), "--rank", rs.c_str(), "--world", ws.c_str(), "--workers", ks.c_str(), nullptr};
                 execv(self_path.c_str(), const_cast<char *const *>(args));
                 std::perror("execv"); _exit(127);
             }
@@ -649,23 +679,24 @@ int main(int argc, char **argv) {
         if (!a.empty() && (a[0] == "prover" || a[0] == "verifier")) { bmode = a[0]; a.erase(a.begin()); }
         if (a.size() >= 2 && a[0] == "--batch") {
             try {
-                uint32_t gpus = 1, rank = 0, world = 0;
+                uint32_t gpus = 1, rank = 0, world = 0, workers = 4;
                 for (size_t k = 2; k + 1 < a.size(); k += 2) {
                     if (a[k] == "--gpus") gpus = (uint32_t)std::stoul(a[k + 1]);
                     else if (a[k] == "--rank") rank = (uint32_t)std::stoul(a[k + 1]);
                     else if (a[k] == "--world") world = (uint32_t)std::stoul(a[k + 1]);
+                    else if (a[k] == "--workers") workers = (uint32_t)std::stoul(a[k + 1]);
                     else { std::fprintf(stderr, "unknown option %s\n", a[k].c_str()); return 2; }
                 }
                 if (world) {
                     FILE *out = fdopen(3, "w");
                     if (!out) { std::fprintf(stderr, "rank %u: no result pipe\n", rank); return 101; }
-                    const int rc = run_batch_rank(bmode, read_batch(a[1]), rank, world, out);
+                    const int rc = run_batch_rank(bmode, read_batch(a[1]), rank, world, workers, out);
                     std::fclose(out);
                     return rc;
                 }
-                if (gpus < 1 || gpus > 64) { std::fprintf(stderr, "--gpus 1..64\n"); return 2; }
+                if (gpus < 1 || gpus > 64 || workers < 1 || workers > 32) { std::fprintf(stderr, "--gpus 1..64, --workers 1..32\n"); return 2; }
                 char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
-                return run_batch(n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]), bmode, a[1], gpus);
+                return run_batch(n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]), bmode, a[1], gpus, workers);
             } catch (const std::exception &e) {
                 std::fprintf(stderr, "%s --batch: %s\n", bmode.c_str(), e.what());
                 return 101;

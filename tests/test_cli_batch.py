@@ -64,8 +64,8 @@ def test_batch_drivers_write_the_files_of_one_run_per_stem(tmp_path):
         assert r.returncode == 0, r.stderr
         counts[s] = int(r.stdout.strip())
     want = _files(a)
-    # (b) native batch, one rank; (c) native batch, two ranks (two processes with their own engine contexts on this card)
-    for name, extra in (("native1", []), ("native2", ["--gpus", "2"])):
+    # (b) native batch, one rank, one worker thread; (c) one rank, four workers (the default); (d) two ranks (two processes on this card, two workers each)
+    for name, extra in (("native1", ["--workers", "1"]), ("native1x4", []), ("native2", ["--gpus", "2", "--workers", "2"])):
         d = _stage(tmp_path / name)
         r = subprocess.run([str(prover_bin), "--batch", "batch.txt"] + extra, cwd=d, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
@@ -81,7 +81,7 @@ def test_batch_drivers_write_the_files_of_one_run_per_stem(tmp_path):
     (d / "less_than.proof").write_bytes(bytes(bad))
     rv = subprocess.run([str(verifier_bin), "--batch", "batch.txt", "--gpus", "2"], cwd=d, env=env, capture_output=True, text=True, timeout=600)
     assert rv.returncode == 1 and "less_than: false" in rv.stdout and rv.stdout.count(": true") == len(STEMS) - 1
-    # (d) the Python driver: one rank, then two ranks over torch.distributed (gloo here: both ranks share this box's one GPU; RCCL needs a GPU per rank)
+    # (e) the Python driver: one rank, then two ranks over torch.distributed (gloo here: both ranks share this box's one GPU; RCCL needs a GPU per rank)
     penv = dict(env, PYTHONPATH=str(ROOT) + os.pathsep + env.get("PYTHONPATH", ""), BPG_BATCH_BACKEND="gloo")
     for name, extra in (("python1", []), ("python2", ["--gpus", "2"])):
         d = _stage(tmp_path / name)
