@@ -1311,6 +1311,10 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
     if (max_multipliers == 0) { I.blind_cancel(); return; }
+    if (I.chain && I.chain->pool) {     // a pool that was destroyed under this context (its threads are gone): fall back to the context's own worker
+        bool gone; { std::lock_guard<std::mutex> lk(I.chain->mu); gone = I.chain->quit; }
+        if (gone) { I.blind_cancel(); I.chain.reset(); I.pool_streams = 0; }
+    }
     using BS = Impl::BlindStream;
     const size_t max_alive = I.pool_streams ? I.pool_streams : (size_t)I.chain_workers * I.chain_lanes + 1;
     while (I.blinds.size() >= max_alive) { I.blind_retire(I.blinds.front()); I.blinds.pop_front(); }     // the oldest gives way
@@ -1340,6 +1344,9 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     I.h_blind[slot].ensure(b->max_draws * 64);
     sd.d.ensure(b->max_draws * 64);
     while (sd.ev.size() < b->max_draws / BS::UP + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sd.ev.push_back(e); }
+    // the device slab changes owner: poison it on the copy stream, ahead of the new owner's uploads, so that a block whose upload were ever dropped
+    // without an error could not hand this proof the previous proof's draws (s_L, s_R shared between two proofs would leak the witness)
+    HIPCHK(hipMemsetAsync(sd.d.p, 0xa5, b->max_draws * 64, sd.copy_st));
     b->raw = I.h_blind[slot].as<uint8_t>();
     b->device = device_; b->copy_st = sd.copy_st; b->d_raw = sd.d.as<uint8_t>(); b->ev = &sd.ev;
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);

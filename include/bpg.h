@@ -233,7 +233,8 @@ bpg_status bpg_ctx_set_chain_lanes(bpg_ctx *ctx, uint32_t lanes);
  * host that proves on several contexts of a GPU (proving streams) sizes ONE pool for its cores instead of a worker per context: e.g. 14 threads with
  * one lane (a chain alone takes 0.30 s at 2^20) and one thread with 6 lanes (0.38 s each) draw twenty chains at once on 15 cores.  An attached
  * context may have max_streams blinding streams alive (bpg_blinding_begin retires the oldest beyond that); bpg_ctx_set_chain_workers / _lanes detach.
- * The pool must outlive its contexts' use of it: detach (pool = NULL) or destroy the contexts first. */
+ * The pool should outlive its contexts' use of it: detach (pool = NULL) or destroy the contexts first.  (bpg_chain_pool_destroy lets the pool finish
+ * what is queued; a context that is still attached afterwards goes back to its own chain worker at its next bpg_blinding_begin.) */
 typedef struct bpg_chain_pool bpg_chain_pool;
 bpg_status bpg_chain_pool_create(uint32_t threads, const uint32_t *lanes /* threads entries, NULL = 1 each */, bpg_chain_pool **out);
 void bpg_chain_pool_destroy(bpg_chain_pool *pool);

@@ -734,6 +734,87 @@ def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     res.free()
 
 
+def test_chain_pool_serves_several_contexts(ctx):
+    """bpg_chain_pool_*: ONE set of chain threads (here one single-lane thread and one that draws three chains in lockstep) draws the blinding
+    streams of every attached context - three contexts proving on their own host threads at once, circuits of two sizes, each keeping the chain of
+    its next proof queued.  Same bytes as stand-alone proofs; a third begin on a context retires its oldest stream; detaching (pool = None, or
+    bpg_ctx_set_chain_workers) and destroying contexts while the pool goes on serving the others changes nothing; a pool destroyed under an attached
+    context sends that context back to its own chain worker."""
+    import threading
+    small = workloads.mimc_preimage(ctx, nbytes=200, seed=21)            # n = 6,804
+    big = workloads.mimc_preimage(ctx, nbytes=900, seed=22)              # n = 28,188
+    seeds = [bytes([40 + k]) * 32 for k in range(4)]
+    want = {}
+    for tag, a in (("small", small), ("big", big)):
+        inst = a.prover.instance()
+        ctx.gens_ensure(a.gens_capacity)
+        r = ctx.upload(inst)
+        want[tag] = [r.prove(a.transcript.state, inst.v_blinding, s, 0)[0] for s in seeds]
+        r.free()
+    pool = bpg.ChainPool([1, 3])
+    assert pool.capacity == 4
+    ctxs = [bpg.Context(0) for _ in range(3)]
+    errs, got = [], {}
+    # every thread gets its own copy of the flattened instance, taken here: a prover (like a context) is used by one host thread at a time
+    jobs = [(("small", small), ("big", big))[k % 2] for k in range(3)]
+    jobs = [(tag, a, a.prover.instance(), a.transcript.state) for tag, a in jobs]
+
+    def work(k):
+        try:
+            c = ctxs[k]
+            tag, a, inst, state = jobs[k]
+            c.gens_ensure(a.gens_capacity)
+            r = c.upload(inst)
+            c.attach_chain_pool(pool, 2)
+            out, queued = [], 0
+            for i, s in enumerate(seeds):
+                while queued < len(seeds) and queued <= i + 1:           # the chain of the next proof is queued before this one is proved
+                    c.blinding_begin(state, inst.v_blinding, seeds[queued], inst.n)
+                    queued += 1
+                out.append(r.prove(state, inst.v_blinding, s, 0)[0])
+            # three begins with two streams allowed: the oldest is retired, its proof draws inside the call; the others are served by the pool
+            for s in seeds[:3]:
+                c.blinding_begin(state, inst.v_blinding, s, inst.n)
+            out += [r.prove(state, inst.v_blinding, s, 0)[0] for s in (seeds[2], seeds[0], seeds[1])]
+            if k == 0:
+                c.attach_chain_pool(None)                                # back to its own worker
+            elif k == 1:
+                c.set_chain_workers(2)                                   # detaches as well
+            c.blinding_begin(state, inst.v_blinding, seeds[3], inst.n)
+            out.append(r.prove(state, inst.v_blinding, seeds[3], 0)[0])
+            r.free()
+            got[k] = (tag, out)
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in range(3):
+        tag, out = got[k]
+        assert out == want[tag] + [want[tag][2], want[tag][0], want[tag][1], want[tag][3]], (k, tag)
+    ctxs[2].close()                                                      # destroyed while attached: the pool goes on
+    inst = small.prover.instance()
+    r = ctxs[0].upload(inst)
+    ctxs[0].attach_chain_pool(pool, 2)
+    ctxs[0].blinding_begin(small.transcript.state, inst.v_blinding, seeds[1], inst.n)
+    assert r.prove(small.transcript.state, inst.v_blinding, seeds[1], 0)[0] == want["small"][1]
+    # the pool is destroyed while a context is still attached (a host's mistake): the context notices and goes back to its own chain worker
+    ctxs[1].attach_chain_pool(pool, 2)
+    pool.close()
+    ctxs[1].gens_ensure(small.gens_capacity)
+    r1 = ctxs[1].upload(inst)
+    ctxs[1].blinding_begin(small.transcript.state, inst.v_blinding, seeds[2], inst.n)
+    assert r1.prove(small.transcript.state, inst.v_blinding, seeds[2], 0)[0] == want["small"][2]
+    ctxs[0].blinding_begin(small.transcript.state, inst.v_blinding, seeds[3], inst.n)
+    assert r.prove(small.transcript.state, inst.v_blinding, seeds[3], 0)[0] == want["small"][3]
+    r.free(); r1.free()
+    for c in ctxs[:2]:
+        c.close()
+
+
 @pytest.mark.parametrize("parts,wnaf,group,budget_gb", [(1, 8, 3, None), (2, 8, 3, None), (4, 8, 3, None), (2, 5, 2, None), (4, 6, 1, None), (4, 3, 5, None), (1, 6, 4, None),
                                                          (4, 8, 3, "0.01"), (4, 8, 2, "0.03"), (2, 7, 3, "0.0001")])
 def test_split_scalar_fold_gives_identical_proofs(parts, wnaf, group, budget_gb, monkeypatch):
