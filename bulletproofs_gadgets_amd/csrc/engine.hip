@@ -240,7 +240,7 @@ struct Engine::Impl {
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
     // tt_table holds the tables of the ORIGINAL generators G[0..M0), H[0..M0) when tt_orig_M0 != 0: they survive across proofs (a circuit
-    // with N <= 2^tt_lg freezes its generators at round 0) and also serve A_I, A_O, S (k_tt_commit3)
+    // with N <= 2^tt_orig_lg freezes its generators at round 0) and also serve A_I, A_O, S (k_tt_commit3)
     uint32_t tt_orig_M0 = 0; const void *tt_orig_gens = nullptr;
     void tt_build(const ge_niels *G, const ge_niels *H, const ge_niels *B, uint32_t M0, bool original) {
         const uint32_t npts = 2 * M0 + 1;
@@ -344,7 +344,9 @@ struct Engine::Impl {
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
-    uint32_t tt_lg = 14;            // freeze the generators once a round is down to 2^tt_lg per side (BPG_TT_LG overrides; 0 = never)
+    uint32_t tt_lg = 12;            // freeze the FOLDED generators once a round is down to 2^tt_lg per side: their window tables are built per proof (BPG_TT_LG; 0 = never)
+    uint32_t tt_orig_lg = 14;       // a circuit of N <= 2^tt_orig_lg freezes the ORIGINAL generators at round 0: those tables are built once and also serve A_I, A_O, S
+                                    // (BPG_TT_ORIG_LG; BPG_TT_LG sets both).  Measured at 2^20 (profiles/r03_tail_start.txt): 12 beats 14 alone and in flight
     PinBuf h_raw, h_small;
     // Speculative blinding streams (Engine::blinding_begin): the leading draws of Prover::prove's TranscriptRng, produced on the context's
     // chain worker (ONE host thread, FIFO) before the circuit is known - or, for a sequence of proofs, while the previous proof's kernels run.
@@ -573,7 +575,8 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (const char *e = std::getenv("BPG_FOLD_TABLE_GB")) { double v = std::atof(e); if (v > 0 && v <= 4096) impl_->fold_table_budget = (uint64_t)(v * (double)(1ull << 30)); }
     if (const char *e = std::getenv("BPG_FOLD_PARTS")) { int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) impl_->fold_parts = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = impl_->tt_orig_lg = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_TT_ORIG_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_orig_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
@@ -1105,12 +1108,12 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
     for (uint32_t round = 0; round < lgN; round++) {
         const uint64_t h = mcur / 2;
         const bool first = round == 0;
-        if (!tt_on && I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) {
+        if (!tt_on && ((I.tt_lg > 0 && mcur <= (1ull << I.tt_lg)) || (first && I.tt_orig_lg > 0 && mcur <= (1ull << I.tt_orig_lg)))) {
             // freeze the generators at this level: window tables for G[0..M0), H[0..M0) and B
             tt_on = true; tt_lgM0 = ceil_log2(mcur); tt_j = 0; tt_cur = 0;
             const uint32_t M0 = (uint32_t)mcur;
             I.tt_f.ensure((size_t)2 * M0 * sizeof(scm)); I.tt_c.ensure((size_t)4 * M0 * sizeof(scm));
-            I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_lg)
+            I.tt_build(Gst, Hst, Bn, M0, Gst == Gtab && Hst == Htab);          // no-op when this context already holds them (N <= 2^tt_orig_lg)
             tt_wide = (Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>()) ? I.wide_ensure(M0) : nullptr;       // original generators: 8-bit windows, built once per device
             BPG_LAUNCH(I, k_tt_factors, dim3(cdiv(M0, 256)), dim3(256), I.yinvpow.as<scm>(), uch_m, (uint32_t)first, (uint32_t)n, M0, to_scm(Gamma), to_scm(Eta),
                        I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, I.tt_c.as<scm>());
@@ -1440,7 +1443,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(256);
 
     // ---- A_I, A_O (do not depend on s_L, s_R): launch, then draw the 2n RNG scalars on the host while they run
-    const bool tabled = I.tt_lg > 0 && N <= (1ull << I.tt_lg) && n > 0;   // the generators have (or get) window tables: A_I, A_O, S are table sums
+    const bool tabled = I.tt_orig_lg > 0 && N <= (1ull << I.tt_orig_lg) && n > 0;   // the generators have (or get) window tables: A_I, A_O, S are table sums
     if (tabled) I.tt_build(Gtab, Htab, Bn, (uint32_t)N, true);
     // the stream of this proof was drawn ahead (a sequence of proofs: its chain ran under the previous proof's kernels) and is complete
     const bool chain_ready = bs && bs->produced.load(std::memory_order_acquire) >= 2 * n;

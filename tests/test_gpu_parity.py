@@ -392,6 +392,27 @@ def test_skewed_witness_distributions(ctx):
     check_against_oracle(ctx, p, t, cs, 512)
 
 
+@pytest.mark.parametrize("tt_lg,orig_lg", [(4, 6), (8, 0), (3, 10), (12, 14)])
+def test_tail_start_of_folded_and_of_original_generators(tt_lg, orig_lg, monkeypatch):
+    """Two thresholds: a circuit of N <= 2^orig_lg freezes the ORIGINAL generators at round 0 (tables built once, A_I / A_O / S are table sums);
+    a larger one folds down to 2^tt_lg and freezes the FOLDED generators there (tables per proof).  Any pair gives the oracle's bytes."""
+    monkeypatch.setenv("BPG_TT_LG", str(tt_lg))
+    monkeypatch.setenv("BPG_TT_ORIG_LG", str(orig_lg))
+    c = bpg.Context(0)
+    try:
+        for a in (workloads.mimc_preimage(c, nbytes=20, seed=3, label=b"MiMCHash"), workloads.bounds_check_64(c, seed=9)):     # N = 1024 (n = 972) and N = 64
+            inst = a.prover.instance()
+            c.gens_ensure(a.gens_capacity)
+            res = c.upload(inst)
+            for seed in (bytes(range(32)), bytes(32)):          # the second proof reuses the tables of the original generators where they were built
+                proof, st_after = res.prove(a.transcript.state, inst.v_blinding, seed, 0)
+                rc, want, st_want = O.prove(O.Gens(a.gens_capacity), a.transcript.state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
+                assert rc == 0 and proof == want and st_after == st_want, (tt_lg, orig_lg, inst.n)
+            res.free()
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("tt_lg,group,split,wnaf,quad", [
     (0, 1, 1, 6, 1), (0, 2, 1, 6, 1), (0, 3, 1, 6, 1), (0, 5, 1, 6, 1), (3, 1, 1, 6, 1), (3, 2, 1, 6, 1), (3, 3, 1, 6, 1),
     (5, 4, 1, 6, 1), (8, 2, 1, 6, 1), (9, 5, 1, 6, 1), (11, 3, 1, 6, 1), (0, 2, 0, 0, 1), (0, 3, 0, 0, 1), (3, 4, 0, 0, 1),
