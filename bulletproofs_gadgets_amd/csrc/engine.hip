@@ -67,6 +67,16 @@ static std::mutex g_table_bytes_mutex;
 static std::map<int, uint64_t> g_table_bytes;
 static uint64_t table_bytes_held(int device) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); return g_table_bytes[device]; }
 static void table_bytes_add(int device, int64_t delta) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); g_table_bytes[device] = (uint64_t)((int64_t)g_table_bytes[device] + delta); }
+// Proofs this process has in flight per device.  Some kernels come in two variants with the same results: one that finishes soonest on an idle
+// device (more lanes per output, redundant doublings) and one with the fewest instructions; a proof that shares the device with others takes
+// the second (measured at 2^20, profiles/r03_tail_start.txt: 0.8 ms per proof sustained; alone the first is 1.7 ms faster).  BPG_FOLD_ADAPT=0 pins the first.
+static std::atomic<int> g_proving[64];
+struct ProvingGuard {
+    std::atomic<int> &c;
+    explicit ProvingGuard(int device) : c(g_proving[(unsigned)device & 63u]) { c.fetch_add(1, std::memory_order_relaxed); }
+    ~ProvingGuard() { c.fetch_sub(1, std::memory_order_relaxed); }
+};
+static bool device_shared(int device) { return g_proving[(unsigned)device & 63u].load(std::memory_order_relaxed) > 1; }
 struct SharedTables {
     int device = 0; uint64_t cap = 0;
     DevBuf gens;
@@ -341,6 +351,7 @@ struct Engine::Impl {
         return true;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
+    bool fold_adapt = true;         // a proof that shares the device with others takes the register fold kernels throughout and sweeps in chunks of 64 (BPG_FOLD_ADAPT=0: never)
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -569,6 +580,7 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BPG_FOLD_ADAPT")) impl_->fold_adapt = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_WIDE_GB")) { double v = std::atof(e); if (v >= 0 && v <= 4096) impl_->tt_wide_budget = (uint64_t)(v * (double)(1ull << 30)); }
@@ -892,6 +904,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
     uint32_t CH = 32;
     if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 2 && v <= 10) CH = 1u << v; }
+    else if (fold_adapt && device_shared(shared->device) && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
     else {
         const uint64_t slots = (uint64_t)sweep_blocks_resident * 256;
         uint64_t rounds = (Mub + slots * 16) / (slots * 32);    // nearest whole number of rounds at 32 entries per thread
@@ -1270,10 +1283,11 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
                 const bool regs = !I.fold_from_memory && (nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15);
-                if (2 * Mr <= I.fold_split_max && nterms >= 1 && nterms <= 7 && !I.fold_from_memory && I.fold_quad) {
+                const uint32_t split_max = (I.fold_adapt && regs && device_shared(I.shared->device)) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
+                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && !I.fold_from_memory && I.fold_quad) {
                     fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
-                } else if (2 * Mr <= I.fold_split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
+                } else if (2 * Mr <= split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
                     fold_kid = KID_k_fold_points_split;
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
                 } else if (regs) {
@@ -1390,6 +1404,7 @@ void Engine::set_chain_lanes(uint32_t n) {
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
 void Engine::test_fail_next_upload() { impl_->test_fail_upload = true; }
 uint64_t Engine::table_bytes() const { return table_bytes_held(device_); }
+
 int Engine::chain_cpu() const { return impl_->last_chain_cpu; }
 
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
@@ -1397,6 +1412,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
     hipStream_t st = I.st;
+    ProvingGuard in_flight(device_);
     const uint64_t n = c->n, m = c->m, q = c->q;
     if (v_blinding.size() != m) throw std::invalid_argument("prove: need one blinding factor per committed variable");
     if (!c->has_witness) throw R1CSException(R1CSError::MissingAssignment, "prove: the uploaded circuit carries no assignments (verifier-side instance)");
