@@ -351,7 +351,8 @@ struct Engine::Impl {
         return true;
     }
     uint32_t fold_split_max = 65536; // folds with at most this many outputs use the 4-wave latency variant (BPG_FOLD_SPLIT overrides; 0 = never)
-    bool fold_adapt = true;         // a proof that shares the device with others takes the register fold kernels throughout and sweeps in chunks of 64 (BPG_FOLD_ADAPT=0: never)
+    uint32_t fold_adapt = 1;        // a proof that shares the device with others takes the register fold kernels throughout and sweeps in chunks of 64 (BPG_FOLD_ADAPT: 0 never, 1 when shared, 2 always)
+    bool shared_variants() const { return fold_adapt == 2 || (fold_adapt == 1 && device_shared(shared->device)); }
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
     bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -580,7 +581,7 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BPG_FOLD_ADAPT")) impl_->fold_adapt = std::atoi(e) != 0;
+    if (const char *e = std::getenv("BPG_FOLD_ADAPT")) { int v = std::atoi(e); if (v >= 0 && v <= 2) impl_->fold_adapt = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
     if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_TT_WIDE_GB")) { double v = std::atof(e); if (v >= 0 && v <= 4096) impl_->tt_wide_budget = (uint64_t)(v * (double)(1ull << 30)); }
@@ -904,7 +905,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
     uint32_t CH = 32;
     if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 2 && v <= 10) CH = 1u << v; }
-    else if (fold_adapt && device_shared(shared->device) && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
+    else if (shared_variants() && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
     else {
         const uint64_t slots = (uint64_t)sweep_blocks_resident * 256;
         uint64_t rounds = (Mub + slots * 16) / (slots * 32);    // nearest whole number of rounds at 32 entries per thread
@@ -1283,7 +1284,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
                 const bool regs = !I.fold_from_memory && (nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15);
-                const uint32_t split_max = (I.fold_adapt && regs && device_shared(I.shared->device)) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
+                const uint32_t split_max = (regs && I.shared_variants()) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
                 if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && !I.fold_from_memory && I.fold_quad) {
                     fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
