@@ -566,10 +566,12 @@ def run_rank(args):
         c_.profile_set(1)       # HIP events around the bucket sweep and the generator folds only (11-13 launches per proof)
     barrier()
     del done_at[:]
+    cpu0 = time.process_time()                               # CPU time of every thread of this process (chain pool and proving threads included)
     t0 = time.perf_counter()
     outs = prove_steps([seed_for(i) for i in range(args.steps)])
     barrier()
     elapsed_local = time.perf_counter() - t0
+    cpu_timed = time.process_time() - cpu0
     # the same timed steps seen from their completion times (rank 0): the region opens with every chain still to be drawn, so nothing can
     # finish for ~0.3 s; what the GPU does meanwhile (A_I, A_O, S under the chains) and how the completions bunch afterwards is the timeline
     done = sorted(done_at)
@@ -860,7 +862,12 @@ def run_rank(args):
                                if prefetch else "every chain is drawn inside its own prove call",
                       "host_threads_per_gpu": {"chain_workers": (len(pool_lanes) if pool is not None else lane_workers * n_streams) if prefetch else 0, "proving": n_streams,
                                                "chain_pool_lanes": pool_lanes if pool is not None else None,
-                                               "note": "chain threads are busy for the whole chain; proving threads sleep in their stream waits (blocking sync)"},
+                                               "cpu_seconds_timed": cpu_timed, "busy_cores_avg": cpu_timed / max(elapsed_local, 1e-9),
+                                               "cpu_seconds_of_chains_one_core_each": args.steps * (2 * inst.n + 8) * 152e-9,
+                                               "note": "chain threads are busy for the whole chain; proving threads sleep in their stream waits (blocking sync). "
+                                                       "cpu_seconds_timed = process CPU time (all threads, rank 0) over the timed steps, busy_cores_avg = that / wall; "
+                                                       "cpu_seconds_of_chains_one_core_each = steps x (2n+8) draws x 152 ns: what the chains cost when each has a core to itself (a lockstep "
+                                                       "thread draws its up to eight chains for 191 ns per draw of all of them)"},
                       "proving_streams_per_gpu": n_streams,
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
