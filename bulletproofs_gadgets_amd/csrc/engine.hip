@@ -243,7 +243,9 @@ struct Engine::Impl {
     uint32_t sort_levels = 2;       // 2 = two-level sort (digits -> coarse partition -> fine sort per bin), 1 = one-level tile sort (BPG_MSM_SORT)
     uint32_t tile_shift = 6, tile_lgmax = 14, tile_threads = 256;   // sort tiles: 2^-tile_shift of an MSM's terms, at most 2^tile_lgmax (BPG_TILE_SHIFT, BPG_TILE_LGMAX, BPG_TILE_THREADS)
     uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 256 CUs x 4 (BPG_SWEEP_RESIDENT)
-    uint32_t msm_cmax = 15;         // widest window: 2^(cmax-1) LDS counters per sorting block (BPG_MSM_CMAX overrides, <= 15)
+    uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps; the one-level sort keeps 2^(cmax-1) LDS counters per block: <= 15)
+    uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (two-level sort only; digits are 16-bit)
+    uint32_t msm_cmin = 2;          // BPG_MSM_CMIN: narrowest window (tests: wide windows on small sums)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
@@ -572,7 +574,8 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     impl_->gens_cache_dir = cfg.gens_cache_dir;
     if (impl_->gens_cache_dir.empty()) { if (const char *e = std::getenv("BPG_GENS_CACHE_DIR")) impl_->gens_cache_dir = e; }
     // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
-    if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 15) impl_->msm_cmax = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 16) impl_->msm_cmax = impl_->msm_cmax_shared = (uint32_t)v; }
+    if (const char *e = std::getenv("BPG_MSM_CMIN")) { int v = std::atoi(e); if (v >= 2 && v <= 16) impl_->msm_cmin = (uint32_t)v; }
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) impl_->sweep_blocks_resident = (uint32_t)cus * 4u; }
     if (const char *e = std::getenv("BPG_SWEEP_RESIDENT")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) impl_->sweep_blocks_resident = (uint32_t)v; }
     if (const char *e = std::getenv("BPG_MSM_SORT")) { int v = std::atoi(e); if (v == 1 || v == 2) impl_->sort_levels = (uint32_t)v; }
@@ -855,9 +858,10 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint32_t total = S.start[S.nseg];
     if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
     uint32_t per = total / nmsm; if (per < 1) per = 1;
-    int cc = (int)ceil_log2(per) - 4; if (cc < 2) cc = 2; if (cc > (int)msm_cmax) cc = (int)msm_cmax;
-    uint32_t maxseg = 1; for (uint32_t k = 0; k < S.nseg; k++) maxseg = std::max(maxseg, S.len[k]);
     const bool two_level = sort_levels == 2;
+    const int cap = std::min<int>(two_level ? 16 : 15, (int)(shared_variants() ? msm_cmax_shared : msm_cmax));
+    int cc = (int)ceil_log2(per) - 4; if (cc < (int)msm_cmin) cc = (int)msm_cmin; if (cc > cap) cc = cap;
+    uint32_t maxseg = 1; for (uint32_t k = 0; k < S.nseg; k++) maxseg = std::max(maxseg, S.len[k]);
     // two-level sort: entry = sign | fb fine bits | 3 segment bits | index in segment -> 28 - fb index bits; at most 512 coarse bins
     uint32_t fb = 0;
     if (two_level) {

@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const u
 // The one-level sort above writes every entry with its own 4-byte store at a position nobody else of the block writes near (a tile holds
 // about one entry per bucket): 8x write amplification, and a histogram matrix of tiles x buckets that is read and written three times.
 // Two levels instead:
-//   k_msm_digits    every signed digit of every term once: dig[window][term] = neg << 15 | |digit|  (2 bytes, coalesced)
+//   k_msm_digits    every signed digit of every term once: dig[window][term] = digit + 2^15  (2 bytes, coalesced; digits of windows up to 16 bits
+//                   wide lie in [-2^15, 2^15), 2^15 = no entry)
 //   k_msm_count1    block (tile of 2^lgTile terms, window): LDS histogram over the CB coarse bins (top bits of the bucket index)
 //   (scan)          exclusive scan of counts1[(msm*W + window)*CB + bin][tile] in that order: where each (bin, tile) run starts
 //   k_msm_scatter1  block (tile, window): orders its entries by coarse bin in LDS and copies the runs out - consecutive lanes write
@@ -126,11 +127,12 @@ __global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32
     const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
     uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
     for (uint32_t j = 0; j < P.W; j++) {
-        const int32_t d = msm_digit_biased(w, P.W, j);
-        const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-        dig[(size_t)j * total + g] = (uint16_t)((neg << 15) | mag);
+        dig[(size_t)j * total + g] = (uint16_t)(msm_digit_biased(w, P.W, j) + 32768);
     }
 }
+// stored digit -> |digit| (0 = no entry) and sign
+__device__ __forceinline__ uint32_t msm_dig_mag(uint32_t x) { return x >= 32768u ? x - 32768u : 32768u - x; }
+__device__ __forceinline__ uint32_t msm_dig_neg(uint32_t x) { return x < 32768u ? 1u : 0u; }
 __device__ __forceinline__ void msm_tile_of(const MsmPlan &P, uint32_t T, uint32_t &m, uint32_t &t, uint32_t &g0, uint32_t &g1) {
     m = 0;
 #pragma unroll
@@ -150,7 +152,7 @@ __global__ void __launch_bounds__(256) k_msm_count1(MsmPlan P, const uint16_t *_
     for (uint32_t gb = g0 + threadIdx.x; gb < g1 + 63u; gb += 4u * blockDim.x) {  // whole waves take part in the ballot of msm_lds_take; four loads in flight
         uint32_t m4[4];
 #pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t g = gb + u * blockDim.x; m4[u] = g < g1 ? (D[g] & 0x7fffu) : 0u; }
+        for (uint32_t u = 0; u < 4; u++) { const uint32_t g = gb + u * blockDim.x; m4[u] = g < g1 ? msm_dig_mag(D[g]) : 0u; }
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) (void)msm_lds_take(hist, m4[u] ? (m4[u] - 1u) >> P.fb : 0u, m4[u] != 0u);
     }
@@ -172,10 +174,10 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
     // one pass of LDS atomics: the slot a term takes inside its coarse bin is kept (16 terms per thread, digit | slot << 16 in a register)
     uint32_t keep[MSM_TILE1_PER];
 #pragma unroll
-    for (uint32_t it = 0; it < MSM_TILE1_PER; it++) { const uint32_t g = g0 + it * 256u + threadIdx.x; keep[it] = g < g1 ? D[g] : 0u; }   // all loads first
+    for (uint32_t it = 0; it < MSM_TILE1_PER; it++) { const uint32_t g = g0 + it * 256u + threadIdx.x; keep[it] = g < g1 ? D[g] : 32768u; }   // all loads first
 #pragma unroll
     for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
-        const uint32_t d = keep[it], mag = d & 0x7fffu;
+        const uint32_t d = keep[it], mag = msm_dig_mag(d);
         const uint32_t slot = msm_lds_take(cnt, mag ? (mag - 1u) >> P.fb : 0u, mag != 0u);
         keep[it] = d | (slot << 16);
     }
@@ -199,11 +201,11 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
 #pragma unroll
     for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
         const uint32_t g = g0 + it * 256u + threadIdx.x;
-        const uint32_t d = keep[it] & 0xffffu, mag = d & 0x7fffu;
+        const uint32_t d = keep[it] & 0xffffu, mag = msm_dig_mag(d);
         if (mag) {
             const uint32_t bkt = mag - 1u, bin = bkt >> P.fb, pos = lbase[bin] + (keep[it] >> 16);
             const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-            staged[pos] = ((d >> 15) << 31) | ((bkt & fmask) << (31u - P.fb)) | (s << (28u - P.fb)) | i;
+            staged[pos] = (msm_dig_neg(d) << 31) | ((bkt & fmask) << (31u - P.fb)) | (s << (28u - P.fb)) | i;
             sbin[pos] = (uint16_t)bin;
         }
     }
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
     // acc = sum (b - lo + 1) B_b ; add lo * run
     ge_ext m = ge_identity();
-    for (int32_t k = 15; k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15
+    for (int32_t k = 31 - __builtin_clz(nb | 1u); k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15: no doublings above its top bit
     partial[t] = ge_add(acc, m);
 }
 

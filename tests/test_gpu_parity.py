@@ -150,6 +150,32 @@ def test_msm_matches_oracle(ctx, count):
     assert ctx.msm_gens(7, s, t) == want
 
 
+@pytest.mark.parametrize("cmin", [16, 15, 9])
+def test_msm_with_wide_windows_on_small_sums(cmin, monkeypatch):
+    """Windows of up to 16 bits (what a 2^20-term sum takes while other proofs share the device: 16 windows instead of 17): the stored digit is
+    digit + 2^15 in 16 bits, -2^15 and the empty digit included.  Forced here on sums small enough for the oracle (BPG_MSM_CMIN)."""
+    monkeypatch.setenv("BPG_MSM_CMIN", str(cmin))
+    c = bpg.Context(0)
+    try:
+        c.gens_ensure(8192)
+        for count in (3, 700, 5000):
+            G, Hh = c.gens_export(5, count)
+            s = [rs(b"ws", i) for i in range(count)]
+            t = [rs(b"wt", i) for i in range(count)]
+            for i in range(0, count, 5):
+                s[i] = bytes(32)
+            for i in range(1, count, 7):
+                t[i] = sc(1)
+            # digits at both ends of a 16-bit window: ...8000 (-2^15 after the recoding), ...7fff, ...ffff, and the same one window up
+            edge = [0x8000, 0x7fff, 0xffff, 0x8000 << 16, 0x7fff << 16, (1 << 253) - 1, R.L - 1, 0x80008000800080008000]
+            for k, v in enumerate(edge):
+                if 2 + k < count:
+                    s[2 + k] = sc(v % R.L)
+            assert c.msm_gens(5, s, t) == O.msm(b"".join(s + t), G + Hh, 1), (cmin, count)
+    finally:
+        c.close()
+
+
 def test_msm_all_ones_and_all_zero(ctx):
     ctx.gens_ensure(8192)
     n = 3000
