@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
     // acc = sum (b - lo + 1) B_b ; add lo * run
     ge_ext m = ge_identity();
-    for (int32_t k = 31 - __builtin_clz(nb | 1u); k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15: no doublings above its top bit
+    for (int32_t k = 31 - __builtin_clz((nb - 1u) | 1u); k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15: no doublings above its top bit
     partial[t] = ge_add(acc, m);
 }
 
