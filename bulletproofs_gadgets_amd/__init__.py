@@ -532,6 +532,20 @@ class Prover:
         _chk(lib().bpg_prover_commit_precomputed(self._h, _exact("v", v, 32), _exact("v_blinding", v_blinding, 32), _exact("commitment", commitment, 32), C.byref(var)))
         return Variable(var.value)
 
+    def defer_commitments(self, on: bool = True):
+        """Extension (bpg_prover_defer_commitments): while on, commit / commit_many / Gadget.setup register their variables and return zero bytes;
+        flush_commitments() computes every pending commitment in one kernel launch and appends them to the transcript in commit order."""
+        _chk(lib().bpg_prover_defer_commitments(self._h, C.c_int32(1 if on else 0)))
+
+    def flush_commitments(self):
+        _chk(lib().bpg_prover_flush_commitments(self._h))
+
+    def commitment(self, index: int) -> bytes:
+        """The commitment of committed variable `index` (commit order), once flushed."""
+        out = _buf(32)
+        _chk(lib().bpg_prover_commitment(self._h, C.c_uint64(index), out))
+        return out.raw
+
     def multiply(self, left, right):
         out = (C.c_uint32 * 3)()
         l, r = LinearCombination.of(left)._c(), LinearCombination.of(right)._c()

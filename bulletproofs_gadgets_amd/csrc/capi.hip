@@ -41,28 +41,47 @@ std::vector<Variable> Prover::commit_many(const std::vector<Scalar> &v, const st
     std::vector<Variable> vars;
     if (!k) return vars;
     if (!engine_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
-    std::vector<uint8_t> vb(k * 32), bb(k * 32);
-    std::vector<Scalar> blind_red(k);
-    for (size_t i = 0; i < k; i++) { v[i].to_bytes(&vb[32 * i]); blind_red[i] = blind[i].is_canonical() ? blind[i] : blind[i].reduced(); blind_red[i].to_bytes(&bb[32 * i]); }
-    engine_->pedersen_commit(k, vb.data(), bb.data(), coms_out.data());
     for (size_t i = 0; i < k; i++) {
-        uint32_t idx = (uint32_t)v_.size();
-        v_.push_back(v[i]); vb_.push_back(blind_red[i]);
-        t_->append_point("V", &coms_out[32 * i]);
+        const uint32_t idx = (uint32_t)v_.size();
+        v_.push_back(v[i]); vb_.push_back(blind[i].is_canonical() ? blind[i] : blind[i].reduced());
         vars.push_back(Variable{Variable::Committed, idx});
+    }
+    V_.resize(v_.size() * 32, 0);
+    if (!deferred_) {
+        const size_t before = v_.size() - k;
+        try { flush_commitments(); }
+        catch (...) { if (flushed_ <= before) { v_.resize(before); vb_.resize(before); V_.resize(before * 32); } throw; }     // a failed call registers nothing
+        std::memcpy(coms_out.data(), &V_[32 * before], k * 32);
     }
     return vars;
 }
 
+// every commitment registered since the last flush: one k_pedersen launch, then the "V" appends in order (the per-call path's transcript)
+void Prover::flush_commitments() {
+    const size_t k = v_.size() - flushed_;
+    if (!k) return;
+    if (!engine_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
+    std::vector<uint8_t> vb(k * 32), bb(k * 32);
+    for (size_t i = 0; i < k; i++) { v_[flushed_ + i].to_bytes(&vb[32 * i]); vb_[flushed_ + i].to_bytes(&bb[32 * i]); }
+    V_.resize(v_.size() * 32, 0);
+    engine_->pedersen_commit(k, vb.data(), bb.data(), &V_[32 * flushed_]);
+    for (size_t i = 0; i < k; i++) t_->append_point("V", &V_[32 * (flushed_ + i)]);
+    flushed_ = v_.size();
+}
+
 Variable Prover::commit_precomputed(const Scalar &v, const Scalar &v_blinding, const uint8_t com[32]) {
+    flush_commitments();
     const uint32_t idx = (uint32_t)v_.size();
     v_.push_back(v); vb_.push_back(v_blinding.is_canonical() ? v_blinding : v_blinding.reduced());
+    V_.insert(V_.end(), com, com + 32);
     t_->append_point("V", com);
+    flushed_ = v_.size();
     return Variable{Variable::Committed, idx};
 }
 
 std::vector<uint8_t> Prover::prove(uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags) {
     if (!engine_) throw DeviceError("this prover has no device context: prove() needs the GPU engine");
+    flush_commitments();
     engine_->gens_ensure(gens_capacity);
     uint64_t N = 1; while (N < aL_.size()) N <<= 1;
     if (gens_capacity < N) throw R1CSException(R1CSError::InvalidGeneratorsLength, "generator capacity below padded circuit size");
@@ -77,6 +96,7 @@ std::vector<uint8_t> Prover::prove(uint64_t gens_capacity, const uint8_t rng_see
 
 void Prover::start_blinding(const uint8_t rng_seed[32], uint64_t max_multipliers) {
     if (!engine_) throw DeviceError("this prover has no device context: start_blinding() needs the GPU engine");
+    flush_commitments();
     engine_->blinding_begin(*t_, vb_, rng_seed, max_multipliers);
 }
 
@@ -353,6 +373,15 @@ bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, c
         if (vars_out) for (uint64_t i = 0; i < k; i++) vars_out[i] = vars[i].packed();
     });
 }
+bpg_status bpg_prover_defer_commitments(bpg_prover *p, int32_t on) { return guard([&] { REQUIRE(p); p->p->defer_commitments(on != 0); }); }
+bpg_status bpg_prover_flush_commitments(bpg_prover *p) { return guard([&] { REQUIRE(p); p->p->flush_commitments(); }); }
+bpg_status bpg_prover_commitment(bpg_prover *p, uint64_t index, uint8_t out[32]) {
+    return guard([&] {
+        REQUIRE(p && out);
+        if (index >= p->p->num_flushed()) throw std::invalid_argument("commitment: no such committed variable (or its commitment is still deferred)");
+        std::memcpy(out, p->p->commitment(index), 32);
+    });
+}
 bpg_status bpg_prover_commit_precomputed(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], const uint8_t com[32], uint32_t *var_out) {
     return guard([&] {
         REQUIRE(p && v && blind && com);
@@ -383,6 +412,7 @@ bpg_status bpg_prover_constrain(bpg_prover *p, const bpg_lc *lc) { return guard(
 bpg_status bpg_prover_instance(bpg_prover *p, bpg_r1cs_instance *out, const uint8_t **v_out, const uint8_t **vb_out) {
     return guard([&] {
         REQUIRE(p && out);
+        p->p->flush_commitments();
         p->flat = p->p->flatten();
         view(p->flat, out);
         const size_t m = p->p->num_committed();

@@ -223,7 +223,8 @@ struct Witness { std::vector<Bytes> scalars, coms; std::vector<uint32_t> vars; B
 struct Setup { std::vector<Bytes> coms, dsc; std::vector<uint32_t> dvars; };
 struct ProverRun {
     std::string name; bpg_ctx *ctx = nullptr; bpg_transcript *tr = nullptr; bpg_prover *p = nullptr;
-    std::map<std::string, Bytes> instance; std::map<std::string, Witness> witness; std::vector<std::string> coms_lines, lines;
+    std::map<std::string, Bytes> instance; std::map<std::string, Witness> witness; std::vector<std::string> lines;
+    std::vector<std::pair<std::string, uint32_t>> coms_lines;      // ("C3-0 = 0x", committed variable): the bytes are read after the one batched commitment launch
     Blindings rnd;
     bool own_ctx = true, quiet = false;              // batch mode: the rank's context is shared by its stems, results go to the summary
     uint64_t out_constraints = 0, out_proof_len = 0;
@@ -241,7 +242,7 @@ struct ProverRun {
 
     const Witness &single(const std::string &w) { const Witness &x = witness.at(w); if (x.scalars.size() != 1) fail("witness var " + w + " is longer than 32 bytes"); return x; }
     Lc lc_of(const std::string &tok) { if (tok[0] == 'W') return Lc::var(single(tok).vars[0]); const Bytes &d = instance.at(tok); if (d.size() > 32) fail("instance var " + tok + " is longer than 32 bytes"); return Lc::constant(be_to_scalar(d)); }
-    void derived_lines(const std::vector<Bytes> &coms, size_t index, int sub) { if (pass == 2) return; for (size_t k = 0; k < coms.size(); k++) coms_lines.push_back("D" + std::to_string(index) + "-" + std::to_string(sub) + "-" + std::to_string(k) + " = 0x" + to_hex(coms[k].data(), 32) + "\n"); }
+    void derived_lines(const std::vector<uint32_t> &vars, size_t index, int sub) { if (pass == 2) return; for (size_t k = 0; k < vars.size(); k++) coms_lines.emplace_back("D" + std::to_string(index) + "-" + std::to_string(sub) + "-" + std::to_string(k) + " = 0x", vars[k]); }
     uint64_t cs_next_multiplier(const Cs &cs) { return cs.b ? bpg_buffer_next_multiplier(cs.b) : bpg_prover_num_multiplications(cs.p); }
 
     // hash_witness (prover.rs:160-190): commit to the MiMC image of a witness and prove the preimage relation -> (image scalar, image var)
@@ -259,7 +260,7 @@ struct ProverRun {
         std::vector<Bytes> dcoms, dsc; std::vector<uint32_t> dvars;
         setup(g, w.scalars, 2, dcoms, dsc, dvars);
         prove(g, cs, w.vars, dsc, dvars);
-        std::vector<Bytes> all{com}; all.insert(all.end(), dcoms.begin(), dcoms.end());
+        std::vector<uint32_t> all{var}; all.insert(all.end(), dvars.begin(), dvars.end());
         derived_lines(all, index, sub);
         return {image, var};
     }
@@ -273,12 +274,12 @@ struct ProverRun {
             const Witness &w = single(parts.at(1));
             new_bounds(g, instance.at(parts.at(2)), instance.at(parts.at(3)));
             est_multipliers += 16 * instance.at(parts.at(3)).size();
-            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dvars, index, 0);
         } else if (op == "HASH") {                                        // prover.rs:278-305
             new_mimc(g, lc_of(parts.at(1)));
             const Witness &w = witness.at(parts.at(2));
             est_multipliers += 972 * (w.scalars.size() + 1);
-            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            setup(g, w.scalars, 2, dcoms, dsc, dvars); prove(g, cs, w.vars, dsc, dvars); derived_lines(dvars, index, 0);
         } else if (op == "MERKLE") {                                      // prover.rs:307-339
             Lc root = lc_of(parts.at(1));
             Tree t = parse_tree(after_two(line));
@@ -300,7 +301,7 @@ struct ProverRun {
             Lc ll = Lc::var(l.vars[0]), rl = Lc::var(r.vars[0]); bpg_lc lv{&ll.t, 1}, rv{&rl.t, 1};
             chk(bpg_less_than_new(&lv, l.scalars[0].data(), &rv, r.scalars[0].data(), &g.h), "LessThan::new");
             est_multipliers += 379;
-            setup(g, {}, 2, dcoms, dsc, dvars); prove(g, cs, {}, dsc, dvars); derived_lines(dcoms, index, 0);
+            setup(g, {}, 2, dcoms, dsc, dvars); prove(g, cs, {}, dsc, dvars); derived_lines(dvars, index, 0);
         } else if (op == "UNEQUAL") {                                     // prover.rs:384-418
             std::string left = parts.at(1), right = parts.at(2); if (left[0] != 'W') std::swap(left, right);
             const Witness &lw = witness.at(left);
@@ -310,7 +311,7 @@ struct ProverRun {
             std::vector<bpg_lc> rv = views(rl); Bytes ra = join(rs);
             chk(bpg_inequality_new(rv.data(), rl.size(), ra.data(), &g.h), "Inequality::new");
             est_multipliers += 2 * lw.scalars.size() + 1;
-            setup(g, lw.scalars, 2 * lw.scalars.size() + 1, dcoms, dsc, dvars); prove(g, cs, lw.vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            setup(g, lw.scalars, 2 * lw.scalars.size() + 1, dcoms, dsc, dvars); prove(g, cs, lw.vars, dsc, dvars); derived_lines(dvars, index, 0);
         } else if (op == "SET_MEMBER") {                                  // prover.rs:420-532
             const std::string &member = parts.at(1); std::vector<std::string> elems(parts.begin() + 2, parts.end());
             std::vector<Bytes> m_scalars; std::vector<Lc> m_lcs;
@@ -336,7 +337,7 @@ struct ProverRun {
             bpg_lc mv{&m_lc.t, 1}; std::vector<bpg_lc> iv = views(i_lcs); Bytes ia = join(i_scalars);
             chk(bpg_set_membership_new(&mv, m_scalar.data(), iv.data(), i_lcs.size(), ia.data(), &g.h), "SetMembership::new");
             est_multipliers += 2 * (w_scalars.size() + i_scalars.size());
-            setup(g, w_scalars, w_scalars.size() + i_scalars.size(), dcoms, dsc, dvars); prove(g, cs, w_vars, dsc, dvars); derived_lines(dcoms, index, 0);
+            setup(g, w_scalars, w_scalars.size() + i_scalars.size(), dcoms, dsc, dvars); prove(g, cs, w_vars, dsc, dvars); derived_lines(dvars, index, 0);
         } else fail("unknown gadget line: '" + line + "'");
     }
 
@@ -376,16 +377,20 @@ struct ProverRun {
         lap("context (HIP init, bases)");
         chk(bpg_transcript_new(reinterpret_cast<const uint8_t *>(name.data()), name.size(), &tr), "Transcript::new");
         chk(bpg_prover_new(ctx, tr, &p), "Prover::new");
+        // every Pedersen commitment of the run - witness variables, hash_witness images, Gadget::setup's derived values: about a thousand for a
+        // 256-leaf tree - in ONE kernel launch when the last one has been registered (bpg.h bpg_prover_defer_commitments): same transcript,
+        // same .coms bytes as one launch per commitment
+        chk(bpg_prover_defer_commitments(p, 1), "defer_commitments");
         for (auto &kv : read_vars(name + ".inst")) instance[kv.first] = kv.second;
         for (auto &kv : read_vars(name + ".wtns")) {                      // assignment_parser.rs:152-169
             Witness w; w.data = kv.second; w.scalars = be_to_scalars(kv.second);
             const size_t k = w.scalars.size();
             Bytes v = join(w.scalars), blind = rnd.take(std::max<size_t>((kv.second.size() + 31) / 32, 1)), coms(32 * k); w.vars.resize(k);
             chk(bpg_prover_commit_many(p, k, v.data(), blind.data(), coms.data(), w.vars.data()), "Prover::commit");
-            for (size_t j = 0; j < k; j++) { w.coms.emplace_back(coms.begin() + 32 * j, coms.begin() + 32 * j + 32); coms_lines.push_back("C" + kv.first.substr(1) + "-" + std::to_string(j) + " = 0x" + to_hex(&coms[32 * j], 32) + "\n"); }
+            for (size_t j = 0; j < k; j++) coms_lines.emplace_back("C" + kv.first.substr(1) + "-" + std::to_string(j) + " = 0x", w.vars[j]);
             witness[kv.first] = w;
         }
-        lap("witness commitments");
+        lap("witness values");
         lines = read_lines(name + ".gadgets");
         Bytes rng_seed(32);
         if (const char *e = std::getenv("BPG_CLI_RNG_SEED")) { rng_seed = from_hex(e); rng_seed.resize(32); }
@@ -395,12 +400,19 @@ struct ProverRun {
         if (tp && std::atoi(tp) == 0) { pass = 0; run_block(0, top, 0); }
         else {
             pass = 1; run_block(0, top, 0);
-            lap("gadget commitments (pass 1)");
+            lap("gadget values (pass 1)");
+            chk(bpg_prover_flush_commitments(p), "flush_commitments");
+            lap("all commitments (one launch)");
             // the transcript is final: start the chain of prove() now.  The estimate only sizes the pinned buffer; a stream that turns out too
             // short (OR blocks add product multipliers) is simply not used
             uint64_t est = est_multipliers + 64; if (saw_or) est = 2 * est + 65536;
             chk(bpg_prover_start_blinding(p, rng_seed.data(), est), "start_blinding");
+            // the generators (0.11 s to derive at 2^20, once per device) are made while pass 2 assembles: nothing in pass 2 touches the context.
+            // The capacity is the estimate's; prove() below asks for the real one, which grows the tables should the estimate have been short
+            struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } early;
+            if (!saw_or && est_multipliers) { bpg_ctx *c = ctx; const uint64_t cap_est = round_pow2(est_multipliers); early.t = std::thread([c, cap_est] { (void)bpg_gens_ensure(c, cap_est); }); }
             pass = 2; run_block(0, top, 0);
+            if (early.t.joinable()) early.t.join();
             if (cache_pos != cache.size()) fail("two-pass driver: pass 2 did not use every commitment of pass 1");
         }
         lap("gadget assembly");
@@ -412,7 +424,10 @@ struct ProverRun {
         uint64_t plen = bpg_proof_size(n, 0); Bytes proof(plen);
         chk(bpg_prover_prove(p, cap, rng_seed.data(), 0, proof.data(), &plen, nullptr), "Prover::prove");
         lap("prove (upload + proof)");
-        { std::ofstream f(name + ".coms"); for (const std::string &l : coms_lines) f << l; }
+        {
+            std::ofstream f(name + ".coms"); uint8_t com[32];
+            for (const auto &l : coms_lines) { chk(bpg_prover_commitment(p, l.second & 0x1fffffffu, com), "commitment"); f << l.first << to_hex(com, 32) << "\n"; }
+        }
         { std::ofstream f(name + ".proof", std::ios::binary); f.write(reinterpret_cast<const char *>(proof.data()), (std::streamsize)plen); }
         out_proof_len = plen;
         return 0;

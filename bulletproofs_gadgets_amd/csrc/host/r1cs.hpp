@@ -171,6 +171,13 @@ public:
     std::vector<Variable> commit_many(const std::vector<Scalar> &v, const std::vector<Scalar> &blind, std::vector<uint8_t> &coms_out);
     // the same for a commitment computed by the caller (no device context needed): registers the variable, appends "V"
     Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const uint8_t com[32]);
+    // extension (include/bpg.h bpg_prover_defer_commitments): while on, commit / commit_many register their variables and return zero bytes;
+    // flush_commitments() makes every pending commitment in ONE kernel launch and appends them to the transcript in the order they were made -
+    // the transcript of the per-call path.  prove(), start_blinding() and commit_precomputed() flush first.
+    void defer_commitments(bool on) { if (!on) flush_commitments(); deferred_ = on; }
+    void flush_commitments();
+    size_t num_flushed() const { return flushed_; }
+    const uint8_t *commitment(size_t i) const { return &V_[32 * i]; }
 
     MulVars multiply(LinearCombination left, LinearCombination right) override {
         Scalar l = eval(left), r = eval(right), o = l * r;
@@ -248,6 +255,8 @@ private:
     Engine *engine_;
     Transcript *t_;
     std::vector<Scalar> aL_, aR_, aO_, v_, vb_;
+    std::vector<uint8_t> V_;            // the commitments, 32 bytes each (zero until flushed)
+    bool deferred_ = false; size_t flushed_ = 0;
     int64_t pending_ = -1;
 };
 

@@ -196,6 +196,15 @@ bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, c
 /* Prover::commit for a host that computes its Pedersen commitments elsewhere (its own PedersenGens, or a prover created without a device
  * context): registers (v, blind) as the next committed variable and appends the given 32-byte commitment to the transcript as "V". */
 bpg_status bpg_prover_commit_precomputed(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], const uint8_t com[32], uint32_t *var_out);
+/* Extension - every commitment of a prover in ONE kernel launch (the reference commits one value at a time, src/gadget.rs:27-35,
+ * src/lalrpop/assignment_parser.rs:152-169; a 512-leaf tree makes a thousand of them).  While deferral is on, the commit calls above and
+ * Gadget::setup register their variables and return ALL-ZERO commitment bytes; the flush computes every pending commitment at once and
+ * appends them to the transcript in the order they were made, which is the transcript the per-call path gives.  Prove, the start of the
+ * blinding chain and the instance export flush first; a host that reads the transcript itself flushes before it does.  The commitment
+ * of committed variable `index` (0-based, in commit order) can be read once it has been flushed. */
+bpg_status bpg_prover_defer_commitments(bpg_prover *p, int32_t on);     /* turning it off flushes */
+bpg_status bpg_prover_flush_commitments(bpg_prover *p);
+bpg_status bpg_prover_commitment(bpg_prover *p, uint64_t index, uint8_t out[32]);
 uint64_t bpg_prover_num_constraints(const bpg_prover *p);                                       /* fork getter, prover.rs:89 */
 uint64_t bpg_prover_num_multiplications(const bpg_prover *p);                                   /* fork getter, prover.rs:92 */
 uint64_t bpg_prover_num_committed(const bpg_prover *p);

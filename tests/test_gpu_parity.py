@@ -176,6 +176,51 @@ def test_msm_with_wide_windows_on_small_sums(cmin, monkeypatch):
         c.close()
 
 
+def test_deferred_commitments_equal_one_launch_per_commitment(ctx):
+    """bpg_prover_defer_commitments (batched witness commitment): the variables are registered at once, the commitments come
+    from ONE k_pedersen launch at the flush and enter the transcript in commit order - same commitments, same transcript, same proof as the
+    reference's one Prover::commit at a time (src/gadget.rs:27-35, src/lalrpop/assignment_parser.rs:152-169)."""
+    class Deferring(bpg.Prover):
+        def __init__(self, c, t):
+            super().__init__(c, t)
+            self.defer_commitments(True)
+
+    for build in (lambda cls: workloads.mimc_preimage(ctx, nbytes=200, seed=11, label=b"MiMCHash", prover_cls=cls),
+                  lambda cls: workloads.bounds_check_64(ctx, seed=12, prover_cls=cls),
+                  lambda cls: workloads.merkle_full_tree(ctx, leaves=4, seed=13, prover_cls=cls)):
+        plain, late = build(bpg.Prover), build(Deferring)
+        m = len(plain.commitments)
+        if m:
+            assert late.commitments == [bytes(32)] * m                      # not known yet
+            with pytest.raises(bpg.BpgError):
+                late.prover.commitment(0)
+            assert late.transcript.state != plain.transcript.state
+        late.prover.flush_commitments()
+        assert [late.prover.commitment(i) for i in range(m)] == plain.commitments
+        assert late.transcript.state == plain.transcript.state
+        with pytest.raises(bpg.BpgError):
+            late.prover.commitment(m)
+        # a commitment made after the flush goes into the next batch; turning deferral off flushes it
+        extra = late.prover.commit(rs(b"dv", 1), rs(b"db", 1))
+        assert extra[0] == bytes(32)
+        late.prover.defer_commitments(False)
+        want = plain.prover.commit(rs(b"dv", 1), rs(b"db", 1))
+        assert late.prover.commitment(m) == want[0] and late.transcript.state == plain.transcript.state
+        seed = bytes(range(32))
+        gens = bpg.BulletproofGens(ctx, max(plain.gens_capacity, 2))
+        assert late.prover.prove(gens, seed) == plain.prover.prove(gens, seed)
+    # prove() flushes what is pending
+    t1, t2 = bpg.Transcript(b"pend"), bpg.Transcript(b"pend")
+    p1, p2 = bpg.Prover(ctx, t1), bpg.Prover(ctx, t2)
+    p2.defer_commitments(True)
+    for p in (p1, p2):
+        _, (a, b, c) = p.commit_many([rs(b"pv", i) for i in range(3)], [rs(b"pb", i) for i in range(3)])
+        l, r, o = p.multiply(a, b)
+        p.constrain(bpg.LinearCombination.of(o) - o)
+    assert p1.prove(bpg.BulletproofGens(ctx, 2), bytes(32)) == p2.prove(bpg.BulletproofGens(ctx, 2), bytes(32))
+    assert [p2.commitment(i) for i in range(3)] == [p1.commitment(i) for i in range(3)]
+
+
 def test_msm_all_ones_and_all_zero(ctx):
     ctx.gens_ensure(8192)
     n = 3000
