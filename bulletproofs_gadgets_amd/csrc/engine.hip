@@ -67,9 +67,11 @@ static std::mutex g_table_bytes_mutex;
 static std::map<int, uint64_t> g_table_bytes;
 static uint64_t table_bytes_held(int device) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); return g_table_bytes[device]; }
 static void table_bytes_add(int device, int64_t delta) { std::lock_guard<std::mutex> lk(g_table_bytes_mutex); g_table_bytes[device] = (uint64_t)((int64_t)g_table_bytes[device] + delta); }
-// Proofs this process has in flight per device.  Some kernels come in two variants with the same results: one that finishes soonest on an idle
-// device (more lanes per output, redundant doublings) and one with the fewest instructions; a proof that shares the device with others takes
-// the second (measured at 2^20, profiles/r03_tail_start.txt: 0.8 ms per proof sustained; alone the first is 1.7 ms faster).  BPG_FOLD_ADAPT=0 pins the first.
+// Proofs this process has in flight per device.  Some steps come in two variants with the same results: one that finishes soonest on an idle
+// device (four lanes per output in the small folds, sweep chunks fitted to whole rounds of resident blocks, 15-bit windows) and one with the
+// fewest instructions (one lane per output, 64-entry chunks, 16-bit windows); a proof that shares the device with others takes the second
+// (Impl::shared_variants; measured at 2^20, profiles/r03_tail_start.txt: 1.9 ms per proof sustained, and 1.7 ms more for a proof alone).
+// BPG_FOLD_ADAPT=0 pins the first set, 2 the second.
 static std::atomic<int> g_proving[64];
 struct ProvingGuard {
     std::atomic<int> &c;

@@ -96,3 +96,39 @@ def test_batch_drivers_write_the_files_of_one_run_per_stem(tmp_path):
         rv = subprocess.run([sys.executable, "-m", "bulletproofs_gadgets_amd.cli", "verifier", "--batch", "batch.txt"] + extra, cwd=d, env=penv,
                             capture_output=True, text=True, timeout=900)
         assert rv.returncode == 0 and [l for l in rv.stdout.strip().splitlines() if l.endswith(": true")] == ["%s: true" % s for s in STEMS], rv.stdout + rv.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_cfg5_batch_of_full_size_merkle_stems(tmp_path):
+    """BASELINE.json config 5 as files: independent 2^20-multiplier proofs from a batch of .gadgets stems (256-leaf MiMC Merkle trees, every leaf a
+    witness hashed by hash_witness: n = 744,552, N = 2^20).  `bpg_prover --batch` with its worker threads (one engine context each, all
+    commitments of a stem in one launch, chains drawn beside the assembly) writes the files of one `bpg_prover NAME` run per stem; `bpg_verifier
+    --batch` accepts them and rejects a tampered one."""
+    from bulletproofs_gadgets_amd import workloads
+    prover_bin, verifier_bin = bpg_build.build_cli()
+    env = dict(os.environ, **ENV)
+    names = ["tree%d" % k for k in range(4)]
+    dirs = {}
+    for mode in ("batch", "per_stem"):
+        d = tmp_path / mode
+        d.mkdir()
+        for k, nm in enumerate(names):
+            n = workloads.merkle_tree_files(str(d / nm), leaves=256, seed=k)
+        (d / "batch.txt").write_text("\n".join(names) + "\n")
+        dirs[mode] = d
+    assert n == 744552
+    r = subprocess.run([str(prover_bin), "--batch", "batch.txt"], cwd=dirs["batch"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines() == ["%s: 1489617 constraints, 1792-byte proof" % nm for nm in names]
+    for nm in names:
+        r = subprocess.run([str(prover_bin), nm], cwd=dirs["per_stem"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and r.stdout.strip() == "1489617", r.stdout + r.stderr
+        for ext in (".coms", ".proof"):
+            assert (dirs["batch"] / (nm + ext)).read_bytes() == (dirs["per_stem"] / (nm + ext)).read_bytes(), nm + ext
+    assert len({(dirs["batch"] / (nm + ".proof")).read_bytes() for nm in names}) == 4          # four different statements
+    rv = subprocess.run([str(verifier_bin), "--batch", "batch.txt"], cwd=dirs["batch"], env=env, capture_output=True, text=True, timeout=600)
+    assert rv.returncode == 0 and rv.stdout.strip().splitlines() == ["%s: true" % nm for nm in names], rv.stdout + rv.stderr
+    bad = bytearray((dirs["batch"] / "tree2.proof").read_bytes()); bad[100] ^= 1
+    (dirs["batch"] / "tree2.proof").write_bytes(bytes(bad))
+    rv = subprocess.run([str(verifier_bin), "--batch", "batch.txt"], cwd=dirs["batch"], env=env, capture_output=True, text=True, timeout=600)
+    assert rv.returncode == 1 and "tree2: false" in rv.stdout and rv.stdout.count(": true") == 3
