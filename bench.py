@@ -70,6 +70,9 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight-lanes", type=int, default=8, help="throughput leg: streams per chain thread in lockstep (1..8)")
     ap.add_argument("--in-flight-steps", type=int, default=24, help="throughput leg: proofs per context")
     ap.add_argument("--in-flight-only", action="store_true", help="only the throughput leg (for profiling the concurrent kernel mix)")
+    ap.add_argument("--profile", choices=("serving", "oneshot"), default="serving", help="bpg_config.profile of every engine context: serving (the headline: a long-lived "
+                    "prover, 51.5 GB of fold tables per device) or oneshot (what a bare bpg_ctx_create gives a drop-in caller: 3 GB of tables)")
+    ap.add_argument("--no-one-shot-leg", action="store_true", help="skip `value_one_shot` (the timed steps once more under the one-shot profile, in a child process)")
     return ap.parse_args(argv)
 
 
@@ -365,7 +368,29 @@ def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
 
 
 # ------------------------------------------------------------------------------------------------ one rank
+def one_shot_leg(args):
+    """`value_one_shot`: the SAME K timed steps (same command, streams, chain pool, seeds) with every context under the ONE-SHOT profile - what a
+    drop-in caller of bpg_ctx_create(device) gets: first fold on width-6 NAF tables of whole scalars (3.0 GB at 2^20), no 8-bit tail tables.  Run as
+    a child process: tables are per process and device, and the serving tables this process holds would count against the one-shot budget."""
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--headline-only", "--profile", "oneshot", "--no-one-shot-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--leaves", str(args.leaves), "--streams", str(args.streams), "--chain-workers", str(args.chain_workers), "--chain-lanes", str(args.chain_lanes),
+           "--chain-pool", args.chain_pool]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BPG_PROFILE"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "one-shot leg failed (rc %d): %s" % (r.returncode, r.stderr[-600:])}
+    d = json.loads(lines[-1])
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "hbm_in_use": d.get("hbm_in_use"),
+            "completions": d.get("completions"), "schedule": d.get("schedule"), "busy_cores_avg": d["config"]["host_threads_per_gpu"]["busy_cores_avg"],
+            "note": "the same timed steps with every engine context under the one-shot profile (bpg_ctx_create's default; blocking stream waits as in the headline), "
+                    "in a child process of this run while this process idles; `value` of the line is the serving profile"}
+
+
 def run_rank(args):
+    ENGINE["profile"] = args.profile
     # the throughput leg runs a dozen engine streams: 8 hardware queues instead of the runtime's default 4 measured 8 % more proofs/s
     # (measured in round 2); read by the HIP runtime at initialisation, so set before torch / the library load it
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
@@ -759,7 +784,11 @@ def run_rank(args):
         except Exception as e:      # noqa: BLE001
             traffic_note = "profiles/pmc_traffic.json unreadable: %r" % (e,)
     peak_fm = ctx.bench_fe_mul(2000)
-    fold_group, tt_lg = int(os.environ.get("BPG_FOLD_GROUP", "3")), int(os.environ.get("BPG_TT_LG", "14"))
+    # the schedule the LIBRARY settled on (bpg_profile_report "_schedule"), not a re-reading of the environment: tail start, fold groups, window caps
+    schedule = ctx.schedule()
+    fold_group, tt_lg = int(schedule["fold_group"]), int(schedule["tt_lg"])
+    if a.gens_capacity <= (1 << int(schedule["tt_orig_lg"])):
+        tt_lg = a.gens_capacity.bit_length() - 1              # the original generators are frozen at round 0: no sweep above the tail
     first_group = min(fold_group, max(a.gens_capacity.bit_length() - 1 - tt_lg, 0))
     rocprof_name = {"k_fold_points_reg": "k_fold_points_reg<%d>" % ((1 << first_group) - 1)}
 
@@ -825,7 +854,7 @@ def run_rank(args):
         # (A_I, A_O, S: 5n terms; L_k, R_k of round k: 2 N_k terms for the rounds above the table-driven tail)
         N, k = a.gens_capacity, 0
         survey_terms = 5 * inst.n
-        while (N >> k) > (1 << tt_lg) and (N >> k) > 1:
+        while (tt_lg == 0 or (N >> k) > (1 << tt_lg)) and (N >> k) > 1:
             survey_terms += 2 * (N >> k); k += 1
         iso = n_streams > 1 and prof_isolated and "k_bucket_chunks" in prof_isolated
         sweeps = (prof_isolated if iso else prof)["k_bucket_chunks"]
@@ -872,7 +901,7 @@ def run_rank(args):
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
            "single_stream": single, "one_host_thread": one_thread, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
-           "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src}
+           "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src, "schedule": schedule, "profile": args.profile}
     if completions is not None:
         out["completions"] = completions
     if hbm_used is not None:
@@ -936,6 +965,11 @@ def run_rank(args):
             out["small_configs"] = small_configs(bpg, workloads, device_index)
         except Exception as e:      # noqa: BLE001
             out["small_configs"] = {"error": repr(e)}
+    if world == 1 and not args.headline_only and not args.no_one_shot_leg and args.profile == "serving":
+        try:
+            out["value_one_shot"] = one_shot_leg(args)
+        except Exception as e:      # noqa: BLE001
+            out["value_one_shot"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline and not args.headline_only:
         log("cpu_baseline: oracle on %d leaves (about %d s on one core) ..." % (args.baseline_leaves, 150 * args.baseline_leaves // 512 + 2))
         cb = cpu_baseline(ctx, bpg, workloads, args.baseline_leaves, {"leaves": args.leaves, "a": a, "inst": inst, "res": res})

@@ -41,16 +41,16 @@ class R1CSInstance(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [(k, C.c_double) for k in ("rng_host", "msm_aiao", "msm_s", "poly", "ipa", "total", "ipa_msm", "ipa_fold", "ipa_sync")]
+    _fields_ = [(k, C.c_double) for k in ("rng_host", "msm_aiao", "msm_s", "poly", "ipa", "total", "ipa_msm", "ipa_fold", "ipa_sync", "shared_variants")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class Config(C.Structure):
-    """bpg_config (include/bpg.h): zero / -1 / None fields fall back to the BPG_* environment variable, then to the profile's default."""
+    """bpg_config (include/bpg.h): zero / None fields fall back to the BPG_* environment variable, then to the profile's default."""
     _fields_ = [("struct_size", C.c_uint32), ("profile", C.c_uint32), ("table_budget_gb", C.c_double), ("chain_workers", C.c_uint32),
-                ("chain_lanes", C.c_uint32), ("blocking_sync", C.c_int32), ("gens_cache_dir", C.c_char_p)]
+                ("chain_lanes", C.c_uint32), ("blocking_sync", C.c_uint32), ("gens_cache_dir", C.c_char_p)]
 
 
 PROFILE_DEFAULT, PROFILE_ONESHOT, PROFILE_SERVING = 0, 1, 2
@@ -63,7 +63,7 @@ def make_config(profile=None, table_budget_gb=None, chain_workers=None, chain_la
     cfg.profile = _PROFILES[profile]
     cfg.table_budget_gb = float(table_budget_gb or 0)
     cfg.chain_workers, cfg.chain_lanes = int(chain_workers or 0), int(chain_lanes or 0)
-    cfg.blocking_sync = -1 if blocking_sync is None else int(bool(blocking_sync))
+    cfg.blocking_sync = 0 if blocking_sync is None else (1 if blocking_sync else 2)      # 0 unset, 1 blocking, 2 spin
     cfg.gens_cache_dir = os.fsencode(gens_cache_dir) if gens_cache_dir else None
     return cfg
 
@@ -84,9 +84,15 @@ def lib():
     """Load (building first if the sources are newer) the shared library."""
     global _lib
     if _lib is None:
-        if not LIB_PATH.exists() or (os.environ.get("BPG_REBUILD") and _build.needs_build()):
-            _build.build()
-        _lib = C.CDLL(str(LIB_PATH))
+        # BPG_LIB_PATH: another build of the SAME sources - the sanitizer builds of tests/hostcheck (host side under ASan/UBSan or TSan) - for the
+        # device-less tests; never a different implementation
+        override = os.environ.get("BPG_LIB_PATH")
+        if override:
+            _lib = C.CDLL(override)
+        else:
+            if not LIB_PATH.exists() or (os.environ.get("BPG_REBUILD") and _build.needs_build()):
+                _build.build()
+            _lib = C.CDLL(str(LIB_PATH))
         _lib.bpg_strerror.restype = C.c_char_p
         _lib.bpg_last_error.restype = C.c_char_p
         for name in ("bpg_proof_size", "bpg_prover_num_constraints", "bpg_prover_num_multiplications", "bpg_prover_num_committed",
@@ -279,11 +285,20 @@ class Context:
     def profile_set(self, mode):
         _chk(lib().bpg_profile_set(self._h, C.c_int32(mode)))
 
-    def profile_report(self):
+    def _report(self):
         import json
         out = _buf(1 << 16)
         _chk(lib().bpg_profile_report(self._h, out, C.c_uint64(1 << 16)))
         return json.loads(out.value.decode())
+
+    def profile_report(self):
+        """bpg_profile_report: {kernel: {count, total_ms, alg_bytes, device_bytes, field_mults}} since the last bpg_profile_set."""
+        return {k: v for k, v in self._report().items() if not k.startswith("_")}
+
+    def schedule(self):
+        """The "_schedule" object of bpg_profile_report: what the knobs, the profile and the table budget of this context settled on (tail start,
+        fold groups, window caps, NAF width and parts in use, epilogue segment, whether the last proof took the shared-device variants)."""
+        return self._report()["_schedule"]
 
     def bench_fe_mul(self, iters=2000):
         r = C.c_double()

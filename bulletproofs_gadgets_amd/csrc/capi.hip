@@ -40,7 +40,7 @@ std::vector<Variable> Prover::commit_many(const std::vector<Scalar> &v, const st
     coms_out.assign(k * 32, 0);
     std::vector<Variable> vars;
     if (!k) return vars;
-    if (!engine_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
+    if (!engine_ && !stub_commitments_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
     for (size_t i = 0; i < k; i++) {
         const uint32_t idx = (uint32_t)v_.size();
         v_.push_back(v[i]); vb_.push_back(blind[i].is_canonical() ? blind[i] : blind[i].reduced());
@@ -60,10 +60,16 @@ std::vector<Variable> Prover::commit_many(const std::vector<Scalar> &v, const st
 void Prover::flush_commitments() {
     const size_t k = v_.size() - flushed_;
     if (!k) return;
-    if (!engine_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
+    if (!engine_ && !stub_commitments_) throw DeviceError("this prover has no device context: Pedersen commitments need the GPU engine");
     std::vector<uint8_t> vb(k * 32), bb(k * 32);
     for (size_t i = 0; i < k; i++) { v_[flushed_ + i].to_bytes(&vb[32 * i]); vb_[flushed_ + i].to_bytes(&bb[32 * i]); }
     V_.resize(v_.size() * 32, 0);
+    if (stub_commitments_) {      // test hook: hash bytes in place of group elements (sanitizer fuzzing of the drivers without a device)
+        for (size_t i = 0; i < k; i++) {
+            Shake256 sh; sh.absorb(reinterpret_cast<const uint8_t *>("bpg stub commitment"), 19); sh.absorb(&vb[32 * i], 32); sh.absorb(&bb[32 * i], 32);
+            sh.squeeze(&V_[32 * (flushed_ + i)], 32);
+        }
+    } else
     engine_->pedersen_commit(k, vb.data(), bb.data(), &V_[32 * flushed_]);
     for (size_t i = 0; i < k; i++) t_->append_point("V", &V_[32 * (flushed_ + i)]);
     flushed_ = v_.size();
@@ -169,14 +175,17 @@ static EngineConfig engine_config(const bpg_config *c) {
     EngineConfig e;
     if (!c) return e;
     // struct_size tells which fields the caller's header knows; the layout only ever grows at the end
-    if (c->struct_size < offsetof(bpg_config, table_budget_gb)) throw std::invalid_argument("bpg_config.struct_size not set");
+    // a field is read when the caller's struct holds ALL of it (offset + size <= struct_size)
     const size_t sz = c->struct_size;
+#define BPG_CFG_HAS(field) (sz >= offsetof(bpg_config, field) + sizeof(c->field))
+    if (!BPG_CFG_HAS(profile)) throw std::invalid_argument("bpg_config.struct_size not set");
     e.profile = c->profile;
-    if (sz >= offsetof(bpg_config, chain_workers)) e.table_budget_gb = c->table_budget_gb;
-    if (sz >= offsetof(bpg_config, chain_lanes)) e.chain_workers = c->chain_workers;
-    if (sz >= offsetof(bpg_config, blocking_sync)) e.chain_lanes = c->chain_lanes;
-    if (sz >= offsetof(bpg_config, gens_cache_dir)) e.blocking_sync = c->blocking_sync;
-    if (sz >= sizeof(bpg_config) && c->gens_cache_dir) e.gens_cache_dir = c->gens_cache_dir;
+    if (BPG_CFG_HAS(table_budget_gb)) e.table_budget_gb = c->table_budget_gb;
+    if (BPG_CFG_HAS(chain_workers)) e.chain_workers = c->chain_workers;
+    if (BPG_CFG_HAS(chain_lanes)) e.chain_lanes = c->chain_lanes;
+    if (BPG_CFG_HAS(blocking_sync)) e.blocking_sync = c->blocking_sync;
+    if (BPG_CFG_HAS(gens_cache_dir) && c->gens_cache_dir) e.gens_cache_dir = c->gens_cache_dir;
+#undef BPG_CFG_HAS
     return e;
 }
 bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config, bpg_ctx **out) {
@@ -226,7 +235,7 @@ void bpg_r1cs_free(bpg_ctx *ctx, bpg_circuit *c) { if (ctx && c) { ctx->engine->
 static void copy_timings(const ProveTimings &t, bpg_timings *o) {
     if (!o) return;
     o->rng_host = t.rng_host; o->msm_aiao = t.msm_aiao; o->msm_s = t.msm_s; o->poly = t.poly; o->ipa = t.ipa; o->total = t.total;
-    o->ipa_msm = t.ipa_msm; o->ipa_fold = t.ipa_fold; o->ipa_sync = t.ipa_sync;
+    o->ipa_msm = t.ipa_msm; o->ipa_fold = t.ipa_fold; o->ipa_sync = t.ipa_sync; o->shared_variants = (double)t.shared_variants;
 }
 
 bpg_status bpg_r1cs_prove_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t ts[BPG_TRANSCRIPT_STATE_BYTES], uint64_t m, const uint8_t *v_blinding,
@@ -359,6 +368,7 @@ bpg_status bpg_prover_new(bpg_ctx *ctx, bpg_transcript *t, bpg_prover **out) {
     return guard([&] { REQUIRE(t && out); bpg_prover *p = new bpg_prover(); p->p = new Prover(ctx ? ctx->engine : nullptr, &t->t); *out = p; });
 }
 void bpg_prover_free(bpg_prover *p) { if (p) { delete p->p; delete p; } }
+bpg_status bpg_test_prover_stub_commitments(bpg_prover *p) { return guard([&] { REQUIRE(p); p->p->test_stub_commitments(); }); }
 bpg_status bpg_prover_commit(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], uint8_t com_out[32], uint32_t *var_out) {
     return bpg_prover_commit_many(p, 1, v, blind, com_out, var_out);
 }

@@ -227,6 +227,7 @@ struct ProverRun {
     std::vector<std::pair<std::string, uint32_t>> coms_lines;      // ("C3-0 = 0x", committed variable): the bytes are read after the one batched commitment launch
     Blindings rnd;
     bool own_ctx = true, quiet = false;              // batch mode: the rank's context is shared by its stems, results go to the summary
+    bool assemble_only = false;                      // tests/hostcheck (sanitizer / fuzz builds): parse and assemble without a device, stop before the proof
     uint64_t out_constraints = 0, out_proof_len = 0;
     int pass = 0;                                    // 0: single pass (commit and assemble line by line); 1: commitments only; 2: assembly only
     std::vector<Setup> cache; size_t cache_pos = 0;  // the commitments of pass 1 in the order pass 2 asks for them
@@ -373,10 +374,11 @@ struct ProverRun {
         auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t0 = now();
         auto lap = [&](const char *what) { if (timing) { double t1 = now(); std::fprintf(stderr, "  %-28s %8.2f ms\n", what, t1 - t0); t0 = t1; } };
-        if (!ctx) chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
+        if (!ctx && !assemble_only) chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
         lap("context (HIP init, bases)");
         chk(bpg_transcript_new(reinterpret_cast<const uint8_t *>(name.data()), name.size(), &tr), "Transcript::new");
         chk(bpg_prover_new(ctx, tr, &p), "Prover::new");
+        if (assemble_only) chk(bpg_test_prover_stub_commitments(p), "stub commitments");        // tests/hostcheck: no device, hash bytes for commitments
         // every Pedersen commitment of the run - witness variables, hash_witness images, Gadget::setup's derived values: about a thousand for a
         // 256-leaf tree - in ONE kernel launch when the last one has been registered (bpg.h bpg_prover_defer_commitments): same transcript,
         // same .coms bytes as one launch per commitment
@@ -406,11 +408,11 @@ struct ProverRun {
             // the transcript is final: start the chain of prove() now.  The estimate only sizes the pinned buffer; a stream that turns out too
             // short (OR blocks add product multipliers) is simply not used
             uint64_t est = est_multipliers + 64; if (saw_or) est = 2 * est + 65536;
-            chk(bpg_prover_start_blinding(p, rng_seed.data(), est), "start_blinding");
+            if (!assemble_only) chk(bpg_prover_start_blinding(p, rng_seed.data(), est), "start_blinding");
             // the generators (0.11 s to derive at 2^20, once per device) are made while pass 2 assembles: nothing in pass 2 touches the context.
             // The capacity is the estimate's; prove() below asks for the real one, which grows the tables should the estimate have been short
             struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } early;
-            if (!saw_or && est_multipliers) { bpg_ctx *c = ctx; const uint64_t cap_est = round_pow2(est_multipliers); early.t = std::thread([c, cap_est] { (void)bpg_gens_ensure(c, cap_est); }); }
+            if (!saw_or && est_multipliers && !assemble_only) { bpg_ctx *c = ctx; const uint64_t cap_est = round_pow2(est_multipliers); early.t = std::thread([c, cap_est] { (void)bpg_gens_ensure(c, cap_est); }); }
             pass = 2; run_block(0, top, 0);
             if (early.t.joinable()) early.t.join();
             if (cache_pos != cache.size()) fail("two-pass driver: pass 2 did not use every commitment of pass 1");
@@ -419,6 +421,7 @@ struct ProverRun {
         out_constraints = bpg_prover_num_constraints(p);
         if (!quiet) std::printf("%llu\n", (unsigned long long)out_constraints);          // prover.rs:89
         const uint64_t n = bpg_prover_num_multiplications(p), cap = round_pow2(n);
+        if (assemble_only) { out_proof_len = 0; return 0; }
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         lap("generators");
         uint64_t plen = bpg_proof_size(n, 0); Bytes proof(plen);
@@ -439,6 +442,7 @@ struct ProverRun {
 struct VerifierRun {
     std::string name; bpg_ctx *ctx = nullptr; bpg_transcript *tr = nullptr; bpg_verifier *v = nullptr;
     bool own_ctx = true, quiet = false;
+    bool assemble_only = false;                      // tests/hostcheck: replay without a device, stop before verify()
     std::map<std::string, Bytes> instance; std::map<std::string, uint32_t> commitments; std::vector<std::string> lines;
 
     std::vector<uint32_t> all_commitments(const std::string &w) {
@@ -548,7 +552,8 @@ struct VerifierRun {
         lines = read_lines(name + ".gadgets");
         Cs top; top.v = v;
         run_block(0, top, 0);
-        chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
+        if (assemble_only) return 0;
+        if (!ctx) chk(bpg_ctx_create(0, &ctx), "bpg_ctx_create");
         const uint64_t cap = round_pow2(bpg_verifier_num_vars(v));
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         Bytes seed(32); { std::ifstream r("/dev/urandom", std::ios::binary); r.read(reinterpret_cast<char *>(seed.data()), 32); }
@@ -587,15 +592,19 @@ int run_batch_rank(const std::string &mode, const std::vector<std::string> &stem
     std::atomic<size_t> next(0);
     std::atomic<int> rc(0);
     std::mutex out_mu; std::string first_error;
+    auto note_error = [&](const std::string &what) { std::lock_guard<std::mutex> lk(out_mu); if (first_error.empty()) first_error = what; rc.store(101); };
     auto work = [&]() {
         bpg_ctx *ctx = nullptr;
-        try {
-            chk(bpg_ctx_create((int32_t)(rank % (uint32_t)ndev), &ctx), "bpg_ctx_create");
-            for (;;) {
-                const size_t k = next.fetch_add(1);
-                if (k >= mine.size()) break;
-                const size_t i = mine[k];
-                char line[128];
+        try { chk(bpg_ctx_create((int32_t)(rank % (uint32_t)ndev), &ctx), "bpg_ctx_create"); }
+        catch (const std::exception &e) { note_error(e.what()); return; }       // no context, no work: the stems go to the other workers
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= mine.size()) break;
+            const size_t i = mine[k];
+            char line[128]; std::string text;
+            // ONE stem per try: a missing or garbled file ends that stem only, as it would end only its own run in the reference's CI
+            // (one prover process per stem, .github/workflows/integration_tests.yml:19-58); the worker goes on with the next stem
+            try {
                 if (mode == "prover") {
                     ProverRun r; r.name = stems[i]; r.ctx = ctx; r.own_ctx = false; r.quiet = true;
                     r.run();
@@ -606,13 +615,15 @@ int run_batch_rank(const std::string &mode, const std::vector<std::string> &stem
                     if (ok != 0) { int want = 0; rc.compare_exchange_strong(want, 1); }
                     std::snprintf(line, sizeof line, "%zu\t%s\n", i, ok == 0 ? "true" : "false");
                 }
-                std::lock_guard<std::mutex> lk(out_mu);
-                std::fputs(line, out); std::fflush(out);
+                text = line;
+            } catch (const std::exception &e) {
+                std::string msg = e.what();
+                for (char &ch : msg) if (ch == '\n' || ch == '\t' || ch == '\r') ch = ' ';
+                text = std::to_string(i) + "\tERROR\t" + msg + "\n";
+                note_error(stems[i] + ": " + msg);
             }
-        } catch (const std::exception &e) {                  // this worker stops; its unfinished stem is reported as FAILED by the parent
             std::lock_guard<std::mutex> lk(out_mu);
-            if (first_error.empty()) first_error = e.what();
-            rc.store(101);
+            std::fputs(text.c_str(), out); std::fflush(out);
         }
         if (ctx) bpg_ctx_destroy(ctx);
     };
@@ -622,6 +633,17 @@ int run_batch_rank(const std::string &mode, const std::vector<std::string> &stem
     for (std::thread &t : th) t.join();
     if (!first_error.empty()) std::fprintf(stderr, "%s --batch (rank %u): %s\n", mode.c_str(), rank, first_error.c_str());
     return rc.load();
+}
+// a ROCm profiler library is preloaded into this process (it initialises the GPU before main(): see run_batch)
+bool profiler_preloaded() {
+    for (const char *var : {"LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "HSA_TOOLS_LIB"}) {
+        const char *v = std::getenv(var);
+        if (!v) continue;
+        if (std::string(var) == "ROCPROFILER_REGISTER_FORCE_LOAD") { if (*v && std::string(v) != "0") return true; continue; }
+        const std::string s(v);
+        if (s.find("rocprof") != std::string::npos || s.find("roctracer") != std::string::npos || s.find("rocprofiler") != std::string::npos) return true;
+    }
+    return false;
 }
 // the batch command: with one GPU it is the rank; with --gpus N it starts N ranks of this executable (nothing here has touched the GPU), reads their
 // result lines from pipes and prints the summary in file order.  Exit code: 0, 1 when a proof was rejected, 101 when a rank failed (the reference panics).
@@ -674,7 +696,8 @@ int run_batch(const std::string &self_path, const std::string &mode, const std::
         }
     }
     for (size_t i = 0; i < stems.size(); i++) {
-        if (result[i].empty()) { std::printf("%s: FAILED\n", stems[i].c_str()); if (rc == 0) rc = 101; continue; }
+        if (result[i].empty()) { std::printf("%s: FAILED\n", stems[i].c_str()); rc = 101; continue; }
+        if (result[i].compare(0, 6, "ERROR\t") == 0) { std::printf("%s: FAILED (%s)\n", stems[i].c_str(), result[i].substr(6).c_str()); rc = 101; continue; }
         if (mode == "prover") {
             const size_t tab = result[i].find('\t');
             std::printf("%s: %s constraints, %s-byte proof\n", stems[i].c_str(), result[i].substr(0, tab).c_str(), result[i].substr(tab + 1).c_str());
@@ -685,6 +708,7 @@ int run_batch(const std::string &self_path, const std::string &mode, const std::
 
 }  // namespace
 
+#ifndef BPG_CLI_NO_MAIN
 int main(int argc, char **argv) {
     std::string self = argv[0]; size_t slash = self.rfind('/'); if (slash != std::string::npos) self = self.substr(slash + 1);
     std::string mode, name;
@@ -695,6 +719,7 @@ int main(int argc, char **argv) {
         if (a.size() >= 2 && a[0] == "--batch") {
             try {
                 uint32_t gpus = 1, rank = 0, world = 0, workers = 4;
+                if (a.size() % 2) { std::fprintf(stderr, "option %s needs a value\n", a.back().c_str()); return 2; }
                 for (size_t k = 2; k + 1 < a.size(); k += 2) {
                     if (a[k] == "--gpus") gpus = (uint32_t)std::stoul(a[k + 1]);
                     else if (a[k] == "--rank") rank = (uint32_t)std::stoul(a[k + 1]);
@@ -710,6 +735,12 @@ int main(int argc, char **argv) {
                     return rc;
                 }
                 if (gpus < 1 || gpus > 64 || workers < 1 || workers > 32) { std::fprintf(stderr, "--gpus 1..64, --workers 1..32\n"); return 2; }
+                if (gpus > 1 && profiler_preloaded()) {
+                    // --gpus N forks and re-executes this image per rank, which is safe only while this process has not touched the GPU; a profiler's
+                    // preloaded library (rocprofv3) initialises the GPU before main(), and an exec from such a process takes the machine down
+                    std::fprintf(stderr, "--gpus %u under a profiler: profile ONE rank instead (rocprofv3 ... -- bpg_prover --batch FILE, or --rank R --world N)\n", gpus);
+                    return 2;
+                }
                 char exe[4096]; const ssize_t n = readlink("/proc/self/exe", exe, sizeof exe - 1);
                 return run_batch(n > 0 ? std::string(exe, (size_t)n) : std::string(argv[0]), bmode, a[1], gpus, workers);
             } catch (const std::exception &e) {
@@ -721,7 +752,12 @@ int main(int argc, char **argv) {
     if (argc == 3 && (std::string(argv[1]) == "prover" || std::string(argv[1]) == "verifier")) { mode = argv[1]; name = argv[2]; }
     else if (argc == 2 && self.find("verifier") != std::string::npos) { mode = "verifier"; name = argv[1]; }
     else if (argc == 2 && self.find("prover") != std::string::npos) { mode = "prover"; name = argv[1]; }
-    else { std::fprintf(stderr, "usage: bpg_prover NAME | bpg_verifier NAME | %s prover|verifier NAME\n", self.c_str()); return 2; }
+    else {
+        std::fprintf(stderr, "usage: bpg_prover NAME | bpg_verifier NAME | %s prover|verifier NAME\n"
+                             "       bpg_prover|bpg_verifier --batch FILE [--gpus N] [--workers W]     (one stem per line of FILE; a stem that fails is reported, the others are still proved;\n"
+                             "                                                                          under a profiler use --gpus 1: the ranks of --gpus N are re-executions of this image)\n", self.c_str());
+        return 2;
+    }
     // a run makes ONE proof per stem: bpg_ctx_create's default, the one-shot profile (15 odd multiples, 7 ms to build at 2^20; no 8-bit tail tables)
     try {
         if (mode == "prover") { ProverRun r; r.name = name; return r.run(); }
@@ -731,3 +767,4 @@ int main(int argc, char **argv) {
         return 101;                                                       // the reference unwrap()s: panic exit code
     }
 }
+#endif  // BPG_CLI_NO_MAIN

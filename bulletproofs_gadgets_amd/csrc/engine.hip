@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -21,6 +22,7 @@
 #include <unistd.h>
 #include "engine.hpp"
 #include "host/fe51.hpp"
+#include "host/chain.hpp"
 #include "hip/kernels.cuh"
 
 namespace bpg {
@@ -199,7 +201,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_msm_plain) X(k_msm_tile_count) X(k_msm_tile_prefix) X(k_msm_tile_scatter) X(k_scan_blocksums) X(k_scan_top) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
@@ -241,12 +243,15 @@ struct Engine::Impl {
     DevBuf gens;                                // view of shared->gens (not owned)
     DevBuf bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, digits, entries1, starts1;
-    uint32_t sort_levels = 2;       // 2 = two-level sort (digits -> coarse partition -> fine sort per bin), 1 = one-level tile sort (BPG_MSM_SORT)
-    uint32_t tile_shift = 6, tile_lgmax = 14, tile_threads = 256;   // sort tiles: 2^-tile_shift of an MSM's terms, at most 2^tile_lgmax (BPG_TILE_SHIFT, BPG_TILE_LGMAX, BPG_TILE_THREADS)
-    uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 256 CUs x 4 (BPG_SWEEP_RESIDENT)
-    uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps; the one-level sort keeps 2^(cmax-1) LDS counters per block: <= 15)
-    uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (two-level sort only; digits are 16-bit)
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
+    uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 4 per CU of the device the context is created on (BPG_SWEEP_RESIDENT overrides)
+    uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps)
+    uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (digits are 16-bit)
+    uint32_t rseg = 8;              // buckets per thread of k_bucket_reduce, a power of two (BPG_RSEG)
+    uint32_t lgch = 0;              // BPG_LGCH: pins the sweep's chunk length to 2^lgch entries (0 = fitted, see msm())
+    bool gens_share = true;         // BPG_GENS_SHARE=0: this context derives (or loads) and keeps generator tables of its own
+    uint32_t profile = 1;           // 1 one-shot, 2 serving (what bpg_config / BPG_PROFILE settled on)
+    bool shared_now = false;        // sampled ONCE per prove()/verify(): does this call take the shared-device variants (shared_variants())
     uint32_t msm_cmin = 2;          // BPG_MSM_CMIN: narrowest window (tests: wide windows on small sums)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
@@ -274,11 +279,17 @@ struct Engine::Impl {
     uint64_t table_budget = 4ull << 30;
     uint64_t tt_wide_budget = 0;                // widest single 8-bit tail table (17.2 GB at M0 = 2^14); 0 = never (the one-shot profile)
     std::string gens_cache_dir;                 // bpg_config.gens_cache_dir / BPG_GENS_CACHE_DIR
-    bool table_fits(uint64_t key, uint64_t bytes) const {          // shared->m held
-        const uint64_t held = table_bytes_held(shared->device);
+    // Reserve `bytes` of the device's table budget (shared->m held).  Check and reservation happen under ONE lock of the per-device byte count, so
+    // two generations of different capacity (each under its own shared->m) cannot both pass the check and overshoot the budget together; the
+    // caller gives the bytes back (table_bytes_add(-bytes)) when its allocation fails.
+    bool table_reserve(uint64_t key, uint64_t bytes) const {
+        std::lock_guard<std::mutex> lk(g_table_bytes_mutex);
+        uint64_t &held = g_table_bytes[shared->device];
         auto it = shared->refused.find(key);
         if (it != shared->refused.end() && held >= it->second) return false;      // failed with this much (or less) held: do not try again
-        return held + bytes <= table_budget;
+        if (held + bytes > table_budget) return false;
+        held += bytes;
+        return true;
     }
     const ge_pniels *wide_ensure(uint32_t M0) {
         const uint64_t bytes = (uint64_t)2 * M0 * TT8_WINDOWS * TT8_MULTS * sizeof(ge_pniels);
@@ -287,17 +298,19 @@ struct Engine::Impl {
         auto it = shared->wide.find(M0);
         if (it != shared->wide.end()) return it->second.as<ge_pniels>();
         const uint64_t key = (1ull << 32) | M0;
-        if (!table_fits(key, bytes)) return nullptr;                             // the 4-bit tables of the context do
+        if (!table_reserve(key, bytes)) return nullptr;                          // the 4-bit tables of the context do
         DevBuf table, bases8;
         try { table.ensure(bytes); bases8.ensure((size_t)2 * M0 * TT8_WINDOWS * sizeof(ge_ext)); }
-        catch (const std::exception &) { (void)hipGetLastError(); table.release(); bases8.release(); shared->refused[key] = table_bytes_held(shared->device); return nullptr; }
+        catch (const std::exception &) {
+            (void)hipGetLastError(); table.release(); bases8.release();
+            table_bytes_add(shared->device, -(int64_t)bytes); shared->refused[key] = table_bytes_held(shared->device); return nullptr;
+        }
         BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
         BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
         bases8.release();
-        shared->wide[M0] = table;
-        table_bytes_add(shared->device, (int64_t)table.cap);
+        shared->wide[M0] = table;                                               // (its bytes were reserved above)
         return table.as<ge_pniels>();
     }
     PinBuf h_naf;
@@ -321,16 +334,18 @@ struct Engine::Impl {
             auto it = shared->odd.find(key);
             if (it != shared->odd.end()) { gens_odd = it->second; return true; }
             const uint64_t bytes = table_bytes(eff_wnaf, eff_parts);
-            if (bytes <= fold_table_budget && table_fits(key, bytes)) {
+            if (bytes <= fold_table_budget && table_reserve(key, bytes)) {
                 try { odd.ensure(bytes); break; }
-                catch (const std::exception &) { (void)hipGetLastError(); odd.release(); shared->refused[key] = table_bytes_held(shared->device); }
+                catch (const std::exception &) { (void)hipGetLastError(); odd.release(); table_bytes_add(shared->device, -(int64_t)bytes); shared->refused[key] = table_bytes_held(shared->device); }
             }
             if (!smaller()) { gens_odd = DevBuf(); return false; }
         }
         const uint32_t key_built = eff_wnaf | (eff_parts << 8);
         const uint32_t NM = 1u << (eff_wnaf - 2), cnt = (uint32_t)(2 * gens_cap), L = fold_part_bits();
+        DevBuf dbl, base;
+        try {
         scratch_ext.ensure((size_t)cnt * sizeof(ge_ext));
-        DevBuf dbl, base; dbl.ensure((size_t)cnt * sizeof(ge_ext));
+        dbl.ensure((size_t)cnt * sizeof(ge_ext));
         if (eff_parts > 1) base.ensure((size_t)cnt * sizeof(ge_ext));
         const dim3 grid(cdiv(cnt, 256)), ngrid(cdiv(cdiv(cnt, NORM_K), 256));
         for (uint32_t part = 0; part < eff_parts; part++) {
@@ -348,9 +363,13 @@ struct Engine::Impl {
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(st));
+        } catch (...) {   // a table that was not built is not published: give its memory and its share of the budget back
+            (void)hipStreamSynchronize(st); dbl.release(); base.release();
+            const uint64_t held = odd.cap; odd.release(); table_bytes_add(shared->device, -(int64_t)held);
+            throw;
+        }
         dbl.release(); base.release();
-        shared->odd[key_built] = odd;
-        table_bytes_add(shared->device, (int64_t)odd.cap);
+        shared->odd[key_built] = odd;                                           // (its bytes were reserved above)
         gens_odd = odd;
         return true;
     }
@@ -358,7 +377,6 @@ struct Engine::Impl {
     uint32_t fold_adapt = 1;        // a proof that shares the device with others takes the register fold kernels throughout and sweeps in chunks of 64 (BPG_FOLD_ADAPT: 0 never, 1 when shared, 2 always)
     bool shared_variants() const { return fold_adapt == 2 || (fold_adapt == 1 && device_shared(shared->device)); }
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
-    bool fold_from_memory = false;  // BPG_FOLD_MEM=1: diagnostic, use the addends-from-memory fold kernel for every group size
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 12;            // freeze the FOLDED generators once a round is down to 2^tt_lg per side: their window tables are built per proof (BPG_TT_LG; 0 = never)
     uint32_t tt_orig_lg = 14;       // a circuit of N <= 2^tt_orig_lg freezes the ORIGINAL generators at round 0: those tables are built once and also serve A_I, A_O, S
@@ -368,107 +386,8 @@ struct Engine::Impl {
     // chain worker (ONE host thread, FIFO) before the circuit is known - or, for a sequence of proofs, while the previous proof's kernels run.
     // snaps[k] = generator state before draw k * SNAP (after the three leading blinding scalars).  Up to two streams are alive per context
     // (the one being consumed and the next), each with its own pinned slab.
-    struct BlindStream {
-        static constexpr uint64_t SNAP = 4096;
-        std::atomic<uint64_t> produced{0};
-        std::atomic<bool> stop{false}, finished{false};
-        std::atomic<int> cpu{-1};
-        uint8_t state[203]; uint8_t seed[32]; std::vector<Scalar> vb;
-        Scalar first[3];
-        std::vector<TranscriptRng> snaps;
-        uint64_t max_draws = 0;
-        int slot = 0; uint8_t *raw = nullptr;
-        // the worker uploads what it has drawn, block by block (UP draws = 4 MB), on the slab's own copy stream; ev[k] completes block k
-        static constexpr uint64_t UP = 65536;
-        int device = 0; hipStream_t copy_st = nullptr; uint8_t *d_raw = nullptr; std::vector<hipEvent_t> *ev = nullptr;
-        std::atomic<uint64_t> uploaded_blocks{0};
-        // first HIP error of this stream's uploads (hipError_t, 0 = none), stored BEFORE uploaded_blocks is published: the device slab is reused
-        // from proof to proof, so a block that was not copied would hand prove() the previous proof's draws - prove() checks and refuses
-        std::atomic<int> err{0};
-        bool inject_fail = false;                                   // bpg_test_fail_next_upload
-        void note(hipError_t e) { if (e != hipSuccess) { int want = 0; err.compare_exchange_strong(want, (int)e, std::memory_order_release); } }
-    };
-    struct ChainWorker {                                     // the context's chain threads: one by default, `workers` draw queued streams side by side
-        std::vector<std::thread> th; std::mutex mu; std::condition_variable cv;
-        std::deque<std::shared_ptr<BlindStream>> pending; bool quit = false;
-        uint32_t lanes = 1;                                  // streams one thread of a context's own worker draws in lockstep (merlin.hpp strobe_rng_bulk64_x8); set before the threads start
-        bool pool = false;                                   // a ChainPool shared by several contexts (its threads carry their own lane counts and outlive the contexts)
-        void stop() { { std::lock_guard<std::mutex> lk(mu); quit = true; } cv.notify_all(); for (std::thread &t : th) if (t.joinable()) t.join(); th.clear(); }
-        // One thread, up to eight streams in lockstep: the sponges of eight proofs in the eight 64-bit lanes of ZMM registers cost a Zen 5 core
-        // 193 ns per draw of all eight against 152 ns for one alone (tools/diag/chain_lanes.py): a chain still takes 0.3 - 0.4 s, a core's chain
-        // THROUGHPUT goes up sixfold.  Streams join at 4,096-draw boundaries as they are queued and leave when they are complete or stopped.
-        static void run_lanes(ChainWorker *w, uint32_t lanes) {
-            struct Lane { std::shared_ptr<BlindStream> b; TranscriptRng rng; uint64_t pos, up; };
-            std::vector<Lane> act;
-            auto upload = [](Lane &L, uint64_t to) {
-                if (to <= L.up) return;
-                BlindStream &b = *L.b;
-                const uint64_t k = L.up / BlindStream::UP;
-                b.note(hipSetDevice(b.device));                                         // lanes of one thread may belong to contexts of different devices
-                b.note(hipMemcpyAsync(b.d_raw + 64 * L.up, b.raw + 64 * L.up, (to - L.up) * 64, hipMemcpyHostToDevice, b.copy_st));
-                b.note(hipEventRecord((*b.ev)[k], b.copy_st));
-                if (b.inject_fail) b.note(hipErrorUnknown);
-                L.up = to;
-                b.uploaded_blocks.store(k + 1, std::memory_order_release);
-            };
-            for (;;) {
-                {   // take what is queued; wait only when there is nothing to draw
-                    std::unique_lock<std::mutex> lk(w->mu);
-                    if (act.empty()) { w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; }
-                    while (act.size() < lanes && !w->pending.empty()) {
-                        std::shared_ptr<BlindStream> b = w->pending.front(); w->pending.pop_front();
-                        b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
-                        act.push_back(Lane{b, b->snaps[0], 0, 0});
-                    }
-                }
-                for (size_t k = 0; k < act.size();) {            // publish; retire what is complete or stopped
-                    Lane &L = act[k]; BlindStream &b = *L.b;
-                    if (L.pos) b.snaps[L.pos / BlindStream::SNAP] = L.rng;
-                    b.produced.store(L.pos, std::memory_order_release);
-                    if (L.pos >= b.max_draws || b.stop.load(std::memory_order_relaxed)) {
-                        upload(L, L.pos);
-                        b.finished.store(true, std::memory_order_release);
-                        act.erase(act.begin() + (ptrdiff_t)k);
-                    } else k++;
-                }
-                if (act.empty()) continue;
-                TranscriptRng *r[8]; uint8_t *dst[8];
-                for (size_t k = 0; k < act.size(); k++) { r[k] = &act[k].rng; dst[k] = act[k].b->raw + 64 * act[k].pos; }
-                TranscriptRng::fill_draws64_multi(r, dst, (uint32_t)act.size(), BlindStream::SNAP);
-                for (Lane &L : act) { L.pos += BlindStream::SNAP; if (L.pos % BlindStream::UP == 0) upload(L, L.pos); }
-            }
-        }
-        static void run(ChainWorker *w, uint32_t lanes) {
-            if (lanes > 1) { run_lanes(w, lanes); return; }
-            for (;;) {
-                std::shared_ptr<BlindStream> b;
-                { std::unique_lock<std::mutex> lk(w->mu); w->cv.wait(lk, [&] { return w->quit || !w->pending.empty(); }); if (w->pending.empty()) return; b = w->pending.front(); w->pending.pop_front(); }
-                b->cpu.store(sched_getcpu(), std::memory_order_relaxed);
-                b->note(hipSetDevice(b->device));
-                TranscriptRng rng = b->snaps[0];
-                uint64_t pos = 0, up = 0;                                               // up: draws handed to the copy stream
-                auto upload = [&](uint64_t to) {                                        // block [up, to) -> device, then its event
-                    if (to <= up) return;
-                    const uint64_t k = up / BlindStream::UP;
-                    b->note(hipMemcpyAsync(b->d_raw + 64 * up, b->raw + 64 * up, (to - up) * 64, hipMemcpyHostToDevice, b->copy_st));
-                    b->note(hipEventRecord((*b->ev)[k], b->copy_st));
-                    if (b->inject_fail) b->note(hipErrorUnknown);
-                    up = to;
-                    b->uploaded_blocks.store(k + 1, std::memory_order_release);
-                };
-                for (;;) {
-                    if (pos) b->snaps[pos / BlindStream::SNAP] = rng;                       // state before draw pos (snaps[0] was set by the caller)
-                    b->produced.store(pos, std::memory_order_release);                  // draws [0, pos) and snapshots up to pos are published
-                    if (pos >= b->max_draws || b->stop.load(std::memory_order_relaxed)) break;
-                    rng.fill_draws64(b->raw + 64 * pos, BlindStream::SNAP);
-                    pos += BlindStream::SNAP;
-                    if (pos % BlindStream::UP == 0) upload(pos);
-                }
-                upload(pos);                                                            // the last, shorter block (or what was drawn before a stop)
-                b->finished.store(true, std::memory_order_release);
-            }
-        }
-    };
+    using BlindStream = bpg::BlindStream;                    // host/chain.hpp: the stream, its worker loops and the publication protocol (no HIP in there)
+    using ChainWorker = bpg::ChainWorker;
     std::shared_ptr<ChainWorker> chain;                     // the context's own worker, or the ChainPool it is attached to
     uint32_t pool_streams = 0;                              // attached to a pool: blinding streams this context may have alive
     uint32_t chain_workers = 1;                             // threads of the chain worker (bpg_ctx_set_chain_workers / BPG_CHAIN_WORKERS); alive streams <= workers * lanes + 1
@@ -543,58 +462,98 @@ struct Engine::Impl {
                        const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0);
 };
 
+// Environment knobs are read ONCE, here, before anything touches the device: a value that does not parse or lies outside its range is an error
+// of the call that creates the context (std::invalid_argument -> BPG_ERR_INVALID_ARGUMENT), never a silent default and never a fault later on
+// the hot path (round 3 read BPG_RSEG with atoi on every MSM call and divided by it).
+namespace {
+bool env_present(const char *name) { const char *e = std::getenv(name); return e && *e; }
+long env_int_strict(const char *name, long lo, long hi) {
+    const char *e = std::getenv(name);
+    char *end = nullptr; errno = 0;
+    const long v = std::strtol(e, &end, 10);
+    if (errno || end == e || *end != '\0' || v < lo || v > hi)
+        throw std::invalid_argument(std::string(name) + "=" + e + ": expected an integer in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+    return v;
+}
+double env_double_strict(const char *name, double lo, double hi) {
+    const char *e = std::getenv(name);
+    char *end = nullptr; errno = 0;
+    const double v = std::strtod(e, &end);
+    if (errno || end == e || *end != '\0' || !(v >= lo) || !(v <= hi))
+        throw std::invalid_argument(std::string(name) + "=" + e + ": expected a number in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]");
+    return v;
+}
+template <class T> void env_set(const char *name, long lo, long hi, T &out) { if (env_present(name)) out = (T)env_int_strict(name, lo, hi); }
+}  // namespace
+
 Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (cfg.profile > 2) throw std::invalid_argument("bpg_config.profile: 0 (default), 1 (one-shot) or 2 (serving)");
     if (cfg.table_budget_gb < 0 || cfg.table_budget_gb > 4096) throw std::invalid_argument("bpg_config.table_budget_gb: 0 (default) .. 4096");
     if (cfg.chain_workers > 64) throw std::invalid_argument("bpg_config.chain_workers: 0 (default), 1..64");
     if (cfg.chain_lanes > 8) throw std::invalid_argument("bpg_config.chain_lanes: 0 (default), 1..8");
+    if (cfg.blocking_sync > 2) throw std::invalid_argument("bpg_config.blocking_sync: 0 (default), 1 (blocking) or 2 (spin)");
+    // What the host chose (bpg_config): the struct first, then the environment variable, then the profile's default.  Everything is settled
+    // in this local Impl before the first HIP call, so a bad knob costs nothing and leaks nothing.
+    std::unique_ptr<Impl> K(new Impl());
+    uint32_t blocking = cfg.blocking_sync;                      // 0 unset, 1 blocking, 2 spin
+    if (blocking == 0 && env_present("BPG_SYNC_BLOCKING")) blocking = env_int_strict("BPG_SYNC_BLOCKING", 0, 1) ? 1u : 2u;
+    uint32_t profile = cfg.profile;
+    if (profile == 0) { if (const char *e = std::getenv("BPG_PROFILE")) profile = (!std::strcmp(e, "serving") || !std::strcmp(e, "2")) ? 2u : 1u; else profile = 1u; }
+    // one-shot (the default of a bare bpg_ctx_create): width-6 NAF fold tables on whole scalars (3.0 GB at 2^20, built in 7 ms), no 8-bit tail
+    // tables, 4 GB of tables in all; serving: width-8 NAF on scalars cut in four (51.5 GB at 2^20, 0.12 s), 8-bit tail tables (17.2 GB at 2^14), 96 GB
+    if (profile == 2) { K->fold_wnaf = 8; K->fold_parts = 4; K->tt_wide_budget = 24ull << 30; K->table_budget = 96ull << 30; }
+    else { K->fold_wnaf = 6; K->fold_parts = 1; K->tt_wide_budget = 0; K->table_budget = 4ull << 30; }
+    K->profile = profile;
+    {
+        double gb = cfg.table_budget_gb;
+        if (!(gb > 0) && env_present("BPG_TABLE_GB")) gb = env_double_strict("BPG_TABLE_GB", 0.0, 4096.0);
+        if (gb > 0) K->table_budget = (uint64_t)(gb * (double)(1ull << 30));
+    }
+    K->chain_workers = cfg.chain_workers ? cfg.chain_workers : 1u; if (!cfg.chain_workers) env_set("BPG_CHAIN_WORKERS", 1, 64, K->chain_workers);
+    K->chain_lanes = cfg.chain_lanes ? cfg.chain_lanes : 1u; if (!cfg.chain_lanes) env_set("BPG_CHAIN_LANES", 1, 8, K->chain_lanes);
+    K->gens_cache_dir = cfg.gens_cache_dir;
+    if (K->gens_cache_dir.empty()) { if (const char *e = std::getenv("BPG_GENS_CACHE_DIR")) K->gens_cache_dir = e; }
+    // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
+    if (env_present("BPG_MSM_CMAX")) K->msm_cmax = K->msm_cmax_shared = (uint32_t)env_int_strict("BPG_MSM_CMAX", 4, 16);
+    env_set("BPG_MSM_CMIN", 2, 16, K->msm_cmin);
+    bool resident_set = false;
+    if (env_present("BPG_SWEEP_RESIDENT")) { K->sweep_blocks_resident = (uint32_t)env_int_strict("BPG_SWEEP_RESIDENT", 64, 65536); resident_set = true; }
+    if (env_present("BPG_RSEG")) {
+        const long v = env_int_strict("BPG_RSEG", 1, 1024);
+        if (v & (v - 1)) throw std::invalid_argument("BPG_RSEG: the segment length of the bucket reduction is a power of two in [1, 1024]");
+        K->rseg = (uint32_t)v;
+    }
+    env_set("BPG_LGCH", 2, 10, K->lgch);
+    env_set("BPG_FOLD_SPLIT", 0, 1 << 24, K->fold_split_max);
+    if (env_present("BPG_FOLD_QUAD")) K->fold_quad = env_int_strict("BPG_FOLD_QUAD", 0, 1) != 0;
+    env_set("BPG_FOLD_ADAPT", 0, 2, K->fold_adapt);
+    env_set("BPG_FOLD_GROUP", 1, 5, K->fold_group);
+    if (env_present("BPG_TT_WIDE_GB")) K->tt_wide_budget = (uint64_t)(env_double_strict("BPG_TT_WIDE_GB", 0.0, 4096.0) * (double)(1ull << 30));
+    if (env_present("BPG_FOLD_TABLE_GB")) K->fold_table_budget = (uint64_t)(env_double_strict("BPG_FOLD_TABLE_GB", 0.0, 4096.0) * (double)(1ull << 30));
+    if (env_present("BPG_FOLD_PARTS")) { const long v = env_int_strict("BPG_FOLD_PARTS", 1, 4); if (v == 3) throw std::invalid_argument("BPG_FOLD_PARTS: 1, 2 or 4"); K->fold_parts = (uint32_t)v; }
+    if (env_present("BPG_FOLD_WNAF")) { const long v = env_int_strict("BPG_FOLD_WNAF", 0, 8); if (v == 1 || v == 2) throw std::invalid_argument("BPG_FOLD_WNAF: 0 (register kernels) or 3..8"); K->fold_wnaf = (uint32_t)v; }
+    if (env_present("BPG_TT_LG")) K->tt_lg = K->tt_orig_lg = (uint32_t)env_int_strict("BPG_TT_LG", 0, 20);
+    env_set("BPG_TT_ORIG_LG", 0, 20, K->tt_orig_lg);
+    if (env_present("BPG_GENS_SHARE")) K->gens_share = env_int_strict("BPG_GENS_SHARE", 0, 1) != 0;
+
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available: the bpg engine has no CPU path");
     if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
     HIPCHK(hipSetDevice(device));
-    // What the host chose (bpg_config): the struct first, then the environment variable, then the profile's default.
-    auto env_int = [](const char *name, int lo, int hi, int &out) { if (const char *e = std::getenv(name)) { const int v = std::atoi(e); if (v >= lo && v <= hi) { out = v; return true; } } return false; };
-    int blocking = cfg.blocking_sync; if (blocking < 0) { blocking = 0; (void)env_int("BPG_SYNC_BLOCKING", 0, 1, blocking); }
-    if (blocking) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
-    impl_ = new Impl();
+    if (blocking == 1) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+    if (!resident_set) {   // blocks of the sweep the device holds at once: 4 per CU of THIS device (a partitioned MI355X shows fewer CUs)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) K->sweep_blocks_resident = (uint32_t)cus * 4u;
+    }
+    impl_ = K.release();
+    try { init_device(); }
+    catch (...) { if (impl_->st) (void)hipStreamDestroy(impl_->st); delete impl_; impl_ = nullptr; throw; }
+}
+
+void Engine::init_device() {
     HIPCHK(hipStreamCreate(&impl_->st));
     stream_ = impl_->st;
-    uint32_t profile = cfg.profile;
-    if (profile == 0) { if (const char *e = std::getenv("BPG_PROFILE")) profile = (!std::strcmp(e, "serving") || !std::strcmp(e, "2")) ? 2u : 1u; else profile = 1u; }
-    // one-shot (the default of a bare bpg_ctx_create): width-6 NAF fold tables on whole scalars (3.0 GB at 2^20, built in 7 ms), no 8-bit tail
-    // tables, 4 GB of tables in all; serving: width-8 NAF on scalars cut in four (51.5 GB at 2^20, 0.12 s), 8-bit tail tables (17.2 GB at 2^14), 96 GB
-    if (profile == 2) { impl_->fold_wnaf = 8; impl_->fold_parts = 4; impl_->tt_wide_budget = 24ull << 30; impl_->table_budget = 96ull << 30; }
-    else { impl_->fold_wnaf = 6; impl_->fold_parts = 1; impl_->tt_wide_budget = 0; impl_->table_budget = 4ull << 30; }
-    {
-        double gb = cfg.table_budget_gb;
-        if (!(gb > 0)) { if (const char *e = std::getenv("BPG_TABLE_GB")) gb = std::atof(e); }
-        if (gb > 0 && gb <= 4096) impl_->table_budget = (uint64_t)(gb * (double)(1ull << 30));
-    }
-    { int v = (int)cfg.chain_workers; if (v == 0) (void)env_int("BPG_CHAIN_WORKERS", 1, 64, v); if (v != 0) impl_->chain_workers = (uint32_t)v; }
-    { int v = (int)cfg.chain_lanes; if (v == 0) (void)env_int("BPG_CHAIN_LANES", 1, 8, v); if (v != 0) impl_->chain_lanes = (uint32_t)v; }
-    impl_->gens_cache_dir = cfg.gens_cache_dir;
-    if (impl_->gens_cache_dir.empty()) { if (const char *e = std::getenv("BPG_GENS_CACHE_DIR")) impl_->gens_cache_dir = e; }
-    // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
-    if (const char *e = std::getenv("BPG_MSM_CMAX")) { int v = std::atoi(e); if (v >= 4 && v <= 16) impl_->msm_cmax = impl_->msm_cmax_shared = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_MSM_CMIN")) { int v = std::atoi(e); if (v >= 2 && v <= 16) impl_->msm_cmin = (uint32_t)v; }
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) impl_->sweep_blocks_resident = (uint32_t)cus * 4u; }
-    if (const char *e = std::getenv("BPG_SWEEP_RESIDENT")) { int v = std::atoi(e); if (v >= 64 && v <= 65536) impl_->sweep_blocks_resident = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_MSM_SORT")) { int v = std::atoi(e); if (v == 1 || v == 2) impl_->sort_levels = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TILE_SHIFT")) { int v = std::atoi(e); if (v >= 0 && v <= 10) impl_->tile_shift = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TILE_LGMAX")) { int v = std::atoi(e); if (v >= 10 && v <= 20) impl_->tile_lgmax = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TILE_THREADS")) { int v = std::atoi(e); if (v == 256 || v == 512 || v == 1024) impl_->tile_threads = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_FOLD_SPLIT")) impl_->fold_split_max = (uint32_t)std::atoi(e);
-    if (const char *e = std::getenv("BPG_FOLD_QUAD")) impl_->fold_quad = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BPG_FOLD_ADAPT")) { int v = std::atoi(e); if (v >= 0 && v <= 2) impl_->fold_adapt = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_FOLD_MEM")) impl_->fold_from_memory = std::atoi(e) != 0;
-    if (const char *e = std::getenv("BPG_FOLD_GROUP")) { int v = std::atoi(e); if (v >= 1 && v <= 5) impl_->fold_group = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TT_WIDE_GB")) { double v = std::atof(e); if (v >= 0 && v <= 4096) impl_->tt_wide_budget = (uint64_t)(v * (double)(1ull << 30)); }
-    if (const char *e = std::getenv("BPG_FOLD_TABLE_GB")) { double v = std::atof(e); if (v > 0 && v <= 4096) impl_->fold_table_budget = (uint64_t)(v * (double)(1ull << 30)); }
-    if (const char *e = std::getenv("BPG_FOLD_PARTS")) { int v = std::atoi(e); if (v == 1 || v == 2 || v == 4) impl_->fold_parts = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_FOLD_WNAF")) { int v = std::atoi(e); if (v == 0 || (v >= 3 && v <= 8)) impl_->fold_wnaf = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TT_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_lg = impl_->tt_orig_lg = (uint32_t)v; }
-    if (const char *e = std::getenv("BPG_TT_ORIG_LG")) { int v = std::atoi(e); if (v >= 0 && v <= 20) impl_->tt_orig_lg = (uint32_t)v; }
     // Pedersen bases: B_blinding = from_uniform(SHA3-512(compress(B)))  (PedersenGens::default, reference src/bin/prover.rs:53)
     static const uint8_t Bc[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9, 0x61, 0xc5, 0x00, 0x51, 0x5f,
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
@@ -642,8 +601,17 @@ void Engine::profile_set(int mode) { HIPCHK(hipSetDevice(device_)); impl_->prof_
 std::string Engine::profile_report() {
     HIPCHK(hipSetDevice(device_));
     impl_->prof_collect();
-    std::string out = "{";
-    bool first = true;
+    // the effective schedule of this context first (what the knobs, the profile and the table budget settled on): bench.py derives its term
+    // counts from THIS, not from its own reading of the environment
+    char sch[640];
+    std::snprintf(sch, sizeof sch, "{\"_schedule\": {\"profile\": %u, \"tt_lg\": %u, \"tt_orig_lg\": %u, \"fold_group\": %u, \"fold_wnaf\": %u, \"fold_parts\": %u, "
+                  "\"eff_wnaf\": %u, \"eff_parts\": %u, \"fold_adapt\": %u, \"fold_split_max\": %u, \"fold_quad\": %u, \"msm_cmax\": %u, \"msm_cmax_shared\": %u, \"msm_cmin\": %u, "
+                  "\"rseg\": %u, \"lgch\": %u, \"sweep_blocks_resident\": %u, \"shared_variants_last\": %u, \"table_budget\": %llu, \"table_bytes\": %llu}",
+                  impl_->profile, impl_->tt_lg, impl_->tt_orig_lg, impl_->fold_group, impl_->fold_wnaf, impl_->fold_parts, impl_->eff_wnaf, impl_->eff_parts,
+                  impl_->fold_adapt, impl_->fold_split_max, (unsigned)impl_->fold_quad, impl_->msm_cmax, impl_->msm_cmax_shared, impl_->msm_cmin, impl_->rseg, impl_->lgch,
+                  impl_->sweep_blocks_resident, (unsigned)impl_->shared_now, (unsigned long long)impl_->table_budget, (unsigned long long)table_bytes_held(device_));
+    std::string out = sch;
+    bool first = false;
     for (int i = 0; i < KID_COUNT; i++) {
         if (!impl_->prof_count[i]) continue;
         char buf[512];
@@ -698,8 +666,7 @@ void Engine::gens_ensure(uint64_t capacity) {
     // a serial XOF), then 2*capacity Elligator maps + one batched normalisation on the device.
     const uint64_t cap = capacity;
     std::lock_guard<std::mutex> tables_lock(g_tables_mutex);
-    const char *share_env = std::getenv("BPG_GENS_SHARE");              // 0: this context derives (or loads) and keeps tables of its own
-    const bool share = !share_env || std::atoi(share_env) != 0;
+    const bool share = I.gens_share;
     if (share) {   // another context of this device already holds tables of this capacity: adopt them
         auto it = g_tables.find({device_, cap});
         if (it != g_tables.end()) {
@@ -860,13 +827,12 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint32_t total = S.start[S.nseg];
     if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
     uint32_t per = total / nmsm; if (per < 1) per = 1;
-    const bool two_level = sort_levels == 2;
-    const int cap = std::min<int>(two_level ? 16 : 15, (int)(shared_variants() ? msm_cmax_shared : msm_cmax));
+    const int cap = (int)(shared_now ? msm_cmax_shared : msm_cmax);
     int cc = (int)ceil_log2(per) - 4; if (cc < (int)msm_cmin) cc = (int)msm_cmin; if (cc > cap) cc = cap;
     uint32_t maxseg = 1; for (uint32_t k = 0; k < S.nseg; k++) maxseg = std::max(maxseg, S.len[k]);
     // two-level sort: entry = sign | fb fine bits | 3 segment bits | index in segment -> 28 - fb index bits; at most 512 coarse bins
     uint32_t fb = 0;
-    if (two_level) {
+    {
         const uint32_t lgseg = ceil_log2(maxseg);
         if (lgseg > 27) throw std::invalid_argument("msm: segment too long");
         const uint32_t fbmax = std::min<uint32_t>(7, 28 - lgseg);
@@ -875,16 +841,14 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     }
     // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
     const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
-    if (two_level && fb > cmax - 1) fb = cmax - 1;
+    if (fb > cmax - 1) fb = cmax - 1;
     const uint32_t nkeys = nmsm * W * nb;
-    uint32_t seg = 8; if (const char *e = std::getenv("BPG_RSEG")) seg = (uint32_t)std::atoi(e); if (seg > nb) seg = nb; const uint32_t nsegpw = nb / seg;
-    const uint32_t nblocks = cdiv(nkeys, SCAN_CHUNK);
+    const uint32_t seg = std::min(rseg, nb), nsegpw = nb / seg;        // both powers of two (rseg is validated at context creation)
     // tiling plan: the segments of one MSM are contiguous; tiles never span two MSMs
     MsmPlan P; std::memset(&P, 0, sizeof P);
     P.nmsm = nmsm; P.W = W; P.nb = nb; P.fb = fb; P.CB = nb >> fb;
     {
-        uint32_t lg = ceil_log2(per) > tile_shift ? ceil_log2(per) - tile_shift : 0; if (lg < 10) lg = 10; if (lg > tile_lgmax) lg = tile_lgmax;
-        if (two_level) lg = 12;                                 // k_msm_scatter1 stages one tile of entries in LDS (MSM_TILE1_MAX)
+        const uint32_t lg = 12;                                 // k_msm_scatter1 stages one tile of entries in LDS (MSM_TILE1_MAX)
         P.lgTile = lg;
         uint32_t k = 0;
         for (uint32_t m = 0; m < nmsm; m++) {
@@ -904,14 +868,14 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     starts.ensure((size_t)(nkeys + 1) * 4);
     entries.ensure((size_t)(total ? total : 1) * W * 4);
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
-    partial.ensure((size_t)nmsm * W * nsegpw * sizeof(ge_ext));
+    partial.ensure((size_t)2 * nmsm * W * nsegpw * sizeof(ge_ext));       // acc and run of every segment
     // balanced sweep: CH sorted entries per thread.  About 32, adjusted so that the launch's blocks fill the device a whole number of times: the
     // sweep keeps sweep_blocks_resident blocks of 256 threads on the CUs at once (4 waves per SIMD at its register count), and 4.25 rounds of
     // blocks cost what 5 do.  BPG_LGCH pins a power of two instead (diagnostics).
     const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
     uint32_t CH = 32;
-    if (const char *e = std::getenv("BPG_LGCH")) { int v = std::atoi(e); if (v >= 2 && v <= 10) CH = 1u << v; }
-    else if (shared_variants() && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
+    if (lgch) CH = 1u << lgch;
+    else if (shared_now && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
     else {
         const uint64_t slots = (uint64_t)sweep_blocks_resident * 256;
         uint64_t rounds = (Mub + slots * 16) / (slots * 32);    // nearest whole number of rounds at 32 entries per thread
@@ -920,7 +884,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     }
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, CH);
     heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
-    if (two_level) {
+    {
         // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
         const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
         if (nflat64 >= (1ull << 31)) throw std::invalid_argument("msm: too many tiles");
@@ -937,18 +901,6 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
         if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits.as<uint16_t>(), total, starts1.as<uint32_t>(), entries1.as<uint32_t>());
         BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
-    } else {
-        counts.ensure((size_t)(nkeys + 1) * 4); cursor.ensure((size_t)nkeys * 4);
-        blocksum.ensure((size_t)(nblocks + 1) * 4);
-        tile_hist.ensure((size_t)nmsm * W * P.tmax * nb * 4);
-        plain.ensure((size_t)(total ? total : 1) * 32);
-        if (total) BPG_LAUNCH((*this), k_msm_plain, dim3(cdiv(total, 256)), dim3(256), S, P, total, plain.as<uint4>());
-        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_count, k_msm_tile<0>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), (const uint32_t *)nullptr, (uint32_t *)nullptr);
-        BPG_LAUNCH((*this), k_msm_tile_prefix, dim3(cdiv(nkeys, 256)), dim3(256), P, tile_hist.as<uint32_t>(), counts.as<uint32_t>(), nkeys, heavy.as<uint32_t>());
-        BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>());
-        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblocks);
-        BPG_LAUNCH((*this), k_scan_apply, dim3(nblocks), dim3(256), counts.as<uint32_t>(), nkeys, blocksum.as<uint32_t>(), starts.as<uint32_t>(), cursor.as<uint32_t>());
-        if (ntiles) BPG_LAUNCH_LDS((*this), KID_k_msm_tile_scatter, k_msm_tile<1>, dim3(ntiles, W), dim3(tile_threads), nb * 4, S, P, plain.as<uint4>(), tile_hist.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     }
     {
         slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
@@ -967,7 +919,9 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint32_t nred = nmsm * W * nsegpw;
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
     wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
-    BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(256), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw);
+    // a window's block: as many threads as it has segments, at most 512 for a proof alone (shortest chain) and 256 while the device is shared (fewest additions)
+    const uint32_t wthreads = std::max<uint32_t>(64, std::min<uint32_t>(nsegpw, shared_now ? 256u : 512u));
+    BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(wthreads), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw, nred, ceil_log2(seg));
     HIPCHK(hipGetLastError());
     if ((size_t)nmsm * W * sizeof(ge_ext) > WS_SLOT_BYTES) throw std::logic_error("msm: window sums exceed the host slot");
     h_wsums.ensure((size_t)WS_SLOTS * WS_SLOT_BYTES);
@@ -992,6 +946,7 @@ void Engine::msm_gens(uint64_t first, uint64_t count, const uint8_t *s, const ui
     if (first + count > gens_cap_) throw std::invalid_argument("msm_gens: range beyond capacity");
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
+    I.shared_now = I.shared_variants();
     I.small_sc.ensure(2 * count * 32 + 64); I.sLR.ensure(2 * count * sizeof(scm) + 64);
     I.msm_result.ensure(4 * sizeof(ge_ext)); I.comp.ensure(128);
     if (count) {
@@ -1230,7 +1185,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
             // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf) -
             // unless no table fits the budget of this device, in which case the register kernels below fold them
-            const bool use_wnaf = I.fold_wnaf >= 3 && !I.fold_from_memory && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max
+            const bool use_wnaf = I.fold_wnaf >= 3 && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max
                                   && I.odd_ensure();
             if (use_wnaf) {
                 const uint32_t parts = I.eff_parts, L = I.fold_part_bits(), nq = nterms * parts;
@@ -1286,15 +1241,15 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             HIPCHK(hipMemcpyAsync(I.naf.p, hn, (size_t)4 * nterms * 16 * 4, hipMemcpyHostToDevice, st));
             FoldGroup fg; fg.Mr = Mr; fg.nterms = nterms; fg.first_group = g_first; fg.n = (uint32_t)n; fg.top = top;
             int fold_kid = KID_k_fold_points;
-            {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise
+            {   // addends in registers when the group size has an instantiation (r = 1..4), from memory otherwise (r = 5)
                 const dim3 grid(cdiv(2 * Mr, 256)), block(256);
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
-                const bool regs = !I.fold_from_memory && (nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15);
-                const uint32_t split_max = (regs && I.shared_variants()) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
-                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && !I.fold_from_memory && I.fold_quad) {
+                const bool regs = nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15;
+                const uint32_t split_max = (regs && I.shared_now) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
+                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad) {
                     fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
-                } else if (2 * Mr <= split_max && nterms >= 3 && nterms <= 15 && !I.fold_from_memory) {
+                } else if (2 * Mr <= split_max && nterms >= 3 && nterms <= 15) {
                     fold_kid = KID_k_fold_points_split;
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
                 } else if (regs) {
@@ -1368,18 +1323,26 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     I.h_blind[slot].ensure(b->max_draws * 64);
     sd.d.ensure(b->max_draws * 64);
     while (sd.ev.size() < b->max_draws / BS::UP + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sd.ev.push_back(e); }
-    // the device slab changes owner: poison it on the copy stream, ahead of the new owner's uploads, so that a block whose upload were ever dropped
-    // without an error could not hand this proof the previous proof's draws (s_L, s_R shared between two proofs would leak the witness)
-    HIPCHK(hipMemsetAsync(sd.d.p, 0xa5, b->max_draws * 64, sd.copy_st));
+    // The device slab changes owner here.  What keeps this proof from reading the previous owner's draws is BlindStream::err: an upload that
+    // fails is recorded BEFORE its block is published and prove() refuses the stream.  (Round 3 also overwrote the slab with a constant first;
+    // nothing ever checked for that constant, a proof built from it would be no more zero-knowledge than one built from stale draws, and it was
+    // a 128 MB memset per 2^20 proof on the copy stream: removed.)
     b->raw = I.h_blind[slot].as<uint8_t>();
     b->device = device_; b->copy_st = sd.copy_st; b->d_raw = sd.d.as<uint8_t>(); b->ev = &sd.ev;
+    // how a drawn block reaches the device (called on the chain thread; host/chain.hpp publishes the block afterwards): an asynchronous copy on the
+    // slab's own copy stream, then the block's event; the threads of a pool serve contexts of different devices, hence the hipSetDevice
+    b->upload = [](BlindStream &bs, uint64_t from, uint64_t to, uint64_t k) -> int {
+        hipError_t e = hipSetDevice(bs.device);
+        if (e == hipSuccess) e = hipMemcpyAsync(bs.d_raw + 64 * from, bs.raw + 64 * from, (to - from) * 64, hipMemcpyHostToDevice, static_cast<hipStream_t>(bs.copy_st));
+        if (e == hipSuccess) e = hipEventRecord((*static_cast<std::vector<hipEvent_t> *>(bs.ev))[k], static_cast<hipStream_t>(bs.copy_st));
+        return (int)e;
+    };
     b->snaps.assign(b->max_draws / BS::SNAP + 1, rng);
     I.slab_owner[slot] = b;
     I.blinds.push_back(b);
     if (!I.chain) { I.chain = std::make_shared<Impl::ChainWorker>(); I.chain->lanes = I.chain_lanes; (void)keccak_impl(); }
     if (!I.chain->pool) while (I.chain->th.size() < I.chain_workers) I.chain->th.emplace_back(Impl::ChainWorker::run, I.chain.get(), I.chain->lanes);
-    { std::lock_guard<std::mutex> lk(I.chain->mu); I.chain->pending.push_back(b); }
-    I.chain->cv.notify_one();
+    I.chain->push(b);
 }
 // ChainPool: chain threads shared by the contexts attached to it (engine.hpp)
 struct ChainPool::Impl { std::shared_ptr<Engine::Impl::ChainWorker> w; };
@@ -1420,6 +1383,10 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     Impl &I = *impl_;
     hipStream_t st = I.st;
     ProvingGuard in_flight(device_);
+    // the kernel variants of this proof are chosen HERE, once: a proof that enters or leaves prove() on another thread must not flip the
+    // schedule half-way through (ProveTimings::shared_variants reports the choice, so a failing proof can be replayed with BPG_FOLD_ADAPT=0 or 2)
+    I.shared_now = I.shared_variants();
+    if (tm) tm->shared_variants = I.shared_now ? 1u : 0u;
     const uint64_t n = c->n, m = c->m, q = c->q;
     if (v_blinding.size() != m) throw std::invalid_argument("prove: need one blinding factor per committed variable");
     if (!c->has_witness) throw R1CSException(R1CSError::MissingAssignment, "prove: the uploaded circuit carries no assignments (verifier-side instance)");
@@ -1527,7 +1494,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
                     for (auto it = I.blinds.begin(); it != I.blinds.end(); ++it) if (it->get() == bs.get()) { I.blinds.erase(it); break; }
                     throw DeviceError(std::string("upload of the blinding draws failed: ") + hipGetErrorString((hipError_t)uerr));
                 }
-                HIPCHK(hipStreamWaitEvent(st, (*bs->ev)[k], 0));
+                HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
                 BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt);
             } else {
                 rng.fill_draws64(raw + 64 * i, cnt);
@@ -1664,6 +1631,7 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
     HIPCHK(hipSetDevice(device_));
     Impl &I = *impl_;
     hipStream_t st = I.st;
+    I.shared_now = I.shared_variants();
     const uint64_t n = c->n, m = c->m, q = c->q;
     uint64_t N = 1; while (N < n) N <<= 1;
     const uint32_t lgN = ceil_log2(N);

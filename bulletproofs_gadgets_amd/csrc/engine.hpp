@@ -15,6 +15,7 @@ struct DeviceError : std::runtime_error { explicit DeviceError(const std::string
 struct ProveTimings {       // milliseconds, host wall clock around each phase (stream synchronised at phase ends)
     double rng_host = 0, msm_aiao = 0, msm_s = 0, poly = 0, ipa = 0, total = 0;
     double ipa_msm = 0, ipa_fold = 0, ipa_sync = 0;
+    uint32_t shared_variants = 0;   // 1: this proof took the shared-device kernel variants (decided once, when prove() was entered)
 };
 
 struct DeviceCircuit;       // HBM-resident flattened R1CS instance
@@ -26,7 +27,7 @@ struct EngineConfig {
     double table_budget_gb = 0;     // cumulative HBM the precomputed generator multiples of this device may take (BPG_TABLE_GB); 0 unset
     uint32_t chain_workers = 0;     // 0 unset (BPG_CHAIN_WORKERS, else 1)
     uint32_t chain_lanes = 0;       // 0 unset (BPG_CHAIN_LANES, else 1)
-    int32_t blocking_sync = -1;     // -1 unset (BPG_SYNC_BLOCKING, else 0)
+    uint32_t blocking_sync = 0;     // 0 unset (BPG_SYNC_BLOCKING=1/0, else spin), 1 blocking waits, 2 spin waits
     std::string gens_cache_dir;     // empty unset (BPG_GENS_CACHE_DIR, else no cache)
 };
 
@@ -100,6 +101,7 @@ private:
     void *stream_ = nullptr;
     uint64_t gens_cap_ = 0;
     Impl *impl_ = nullptr;
+    void init_device();             // second half of the constructor: everything that touches the GPU
 };
 
 }  // namespace bpg

@@ -22,12 +22,9 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
     return s;
 }
 
-// Sorting the (term, window) entries by bucket without global atomics (device-scope atomics on MI355X resolve beyond the
-// per-XCD L2 and were the slowest part of the MSM): the terms of each MSM are cut into tiles of 2^lgTile terms; block
-// (tile, window) histograms its tile in LDS (LDS atomics) and writes the row H[msm*W+window][tile][0..nb) with plain coalesced
-// stores; k_msm_tile_prefix turns the rows of one key column into exclusive prefixes over the tiles and emits the bucket
-// totals; after the usual scan of the totals, block (tile, window) reloads its row (+ bucket start) into LDS as cursors and
-// scatters its entries.  key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment.
+// Sorting the (term, window) entries by bucket without global atomics (device-scope atomics on MI355X resolve beyond the per-XCD L2 and
+// were the slowest part of the MSM): LDS histograms and LDS-staged runs only, see "two-level sort" below.
+// key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment.
 // Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
@@ -48,54 +45,10 @@ __device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, c
 #pragma unroll
     for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)w[k] + P.bias[k] + carry; w[k] = (uint32_t)t; carry = t >> 32; }
 }
-// biased plain words of every term, once per MSM (the tile kernels run W times over the same scalars)
-__global__ void __launch_bounds__(256) k_msm_plain(MsmSegs S, MsmPlan P, uint32_t total, uint4 *__restrict__ plain) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-    uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
-    plain[2 * (size_t)g] = make_uint4(w[0], w[1], w[2], w[3]);
-    plain[2 * (size_t)g + 1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-template <int PASS>
-__global__ void __launch_bounds__(1024) k_msm_tile(MsmSegs S, MsmPlan P, const uint4 *__restrict__ plain, uint32_t *__restrict__ H,
-                                                  const uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
-    extern __shared__ uint32_t tile_lds[];                   // nb counters (pass 0) or cursors (pass 1)
-    const uint32_t T = blockIdx.x, win = blockIdx.y;
-    uint32_t m = 0;
-#pragma unroll
-    for (uint32_t k = 1; k < 4; k++) if (k < P.nmsm && T >= P.tile_start[k]) m = k;
-    const uint32_t t = T - P.tile_start[m];
-    const uint32_t g0 = P.term_start[m] + (t << P.lgTile);
-    const uint32_t g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
-    const uint32_t mw = m * P.W + win;
-    uint32_t *row = H + ((size_t)mw * P.tmax + t) * P.nb;
-    if (PASS == 0) for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) tile_lds[b] = 0;
-    else for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) tile_lds[b] = row[b] + starts[(size_t)mw * P.nb + b];
-    __syncthreads();
-    // the window's bits sit in one or two of the eight words: read only the 16-byte half (or both halves) that holds them
-    const uint32_t off = msm_off(win, P.W), wd = msm_off(win + 1, P.W) - off, wi = off >> 5, sh = off & 31;
-    for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
-        const uint32_t *pw = reinterpret_cast<const uint32_t *>(plain + 2 * (size_t)g);
-        const uint64_t two = (uint64_t)pw[wi] | ((uint64_t)(wi + 1 < 8 ? pw[wi + 1] : 0u) << 32);
-        const int32_t d = (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
-        if (d == 0) continue;
-        const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-        if (PASS == 0) atomicAdd(&tile_lds[mag - 1], 1u);
-        else {
-            const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-            const uint32_t pos = atomicAdd(&tile_lds[mag - 1], 1u); entries[pos] = (neg << 31) | (s << 27) | i;
-        }
-    }
-    if (PASS == 0) {
-        __syncthreads();
-        for (uint32_t b = threadIdx.x; b < P.nb; b += blockDim.x) row[b] = tile_lds[b];
-    }
-}
-// ------------------------------------------------------------------------------------------------ two-level sort (default)
-// The one-level sort above writes every entry with its own 4-byte store at a position nobody else of the block writes near (a tile holds
-// about one entry per bucket): 8x write amplification, and a histogram matrix of tiles x buckets that is read and written three times.
-// Two levels instead:
+// ------------------------------------------------------------------------------------------------ two-level sort
+// A one-level counting sort (round 1; removed in round 4) writes every entry with its own 4-byte store at a position nobody else of the block
+// writes near (a tile holds about one entry per bucket): 8x write amplification, and a histogram matrix of tiles x buckets that is read and
+// written three times.  Two levels instead:
 //   k_msm_digits    every signed digit of every term once: dig[window][term] = digit + 2^15  (2 bytes, coalesced; digits of windows up to 16 bits
 //                   wide lie in [-2^15, 2^15), 2^15 = no entry)
 //   k_msm_count1    block (tile of 2^lgTile terms, window): LDS histogram over the CB coarse bins (top bits of the bucket index)
@@ -269,20 +222,6 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
     }
 }
 
-// one thread per key: H[mw][t][b] <- sum_{t' < t} H[mw][t'][b], counts[key] <- column total
-__global__ void __launch_bounds__(256) k_msm_tile_prefix(MsmPlan P, uint32_t *__restrict__ H, uint32_t *__restrict__ counts, uint32_t nkeys,
-                                                         uint32_t *__restrict__ heavy_count) {
-    const uint32_t key = blockIdx.x * blockDim.x + threadIdx.x;
-    if (key == 0) *heavy_count = 0;                          // list of k_bucket_combine, filled later on this stream
-    if (key >= nkeys) return;
-    const uint32_t mw = key / P.nb, b = key - mw * P.nb, m = mw / P.W;
-    const uint32_t nt = P.tile_start[m + 1] - P.tile_start[m];
-    uint32_t *col = H + (size_t)mw * P.tmax * P.nb + b;
-    uint32_t run = 0;
-    for (uint32_t t = 0; t < nt; t++) { const uint32_t v = col[(size_t)t * P.nb]; col[(size_t)t * P.nb] = run; run += v; }
-    counts[key] = run;
-}
-
 // exclusive scan of counts[0..nkeys) in three launches (chunk = 2048 keys per block)
 #define SCAN_CHUNK 2048
 __global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restrict__ counts, uint32_t nkeys, uint32_t *__restrict__ blocksum) {
@@ -433,7 +372,16 @@ __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__
     }
 }
 
-// per (msm, window, segment of SEG buckets): sum_b (b+1) * bucket[b] over the segment -> partial
+// Epilogue of a window: S = sum_b (b+1) * bucket[b] over its nb buckets, in two levels of running sums and one weighted tree - no scalar
+// multiplication by a bucket index anywhere (rounds 1-3 added lo * run per segment by double-and-add: 15 doublings + ~7 additions for every 8
+// buckets, more field multiplications than the running sums themselves and a third of the instructions of the sweep it follows).
+//   k_bucket_reduce  thread t = (window, segment of `seg` buckets starting at lo = sg*seg): run_t = sum B_b, acc_t = sum (b - lo + 1) B_b
+//                    (2 additions per bucket); partial[t] = acc_t, partial[total + t] = run_t
+//   k_window_sums    block per window (64..512 threads: two waves per SIMD, 256 VGPRs for three live points and an addition; per = segments per thread, a power of two):
+//                      S = sum_t acc_t + seg * sum_t sg * run_t,    sg = tau * per + j for thread tau
+//                    thread: Q = sum acc_t + seg * sum_j j * run_t (running sums again, 3 additions per segment), R = sum run_t;
+//                    sum_tau tau * R_tau = sum_{tau >= 1} Suf_tau with Suf_tau = sum_{tau' >= tau} R_tau' - a suffix scan over the block
+//                    (wave shuffles, then the wave totals through LDS) instead of multiplications by tau; S = sum_tau (Q_tau + seg*per*Suf_tau).
 __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__ buckets, ge_ext *__restrict__ partial,
                                                      uint32_t nb, uint32_t seg, uint32_t nseg_per_win, uint32_t total) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,26 +389,67 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     uint32_t win = t / nseg_per_win, sg = t % nseg_per_win;
     uint32_t lo = sg * seg;
     const ge_ext *B = buckets + (size_t)win * nb;
-    ge_ext run = ge_identity(), acc = ge_identity();
-    for (int32_t b = (int32_t)(lo + seg) - 1; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
-    // acc = sum (b - lo + 1) B_b ; add lo * run
-    ge_ext m = ge_identity();
-    for (int32_t k = 31 - __builtin_clz((nb - 1u) | 1u); k >= 0; k--) { m = ge_dbl(m); if ((lo >> k) & 1u) m = ge_add(m, run); }   // lo < nb <= 2^15: no doublings above its top bit
-    partial[t] = ge_add(acc, m);
+    ge_ext run = B[lo + seg - 1], acc = run;
+    for (int32_t b = (int32_t)(lo + seg) - 2; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
+    partial[t] = acc; partial[(size_t)total + t] = run;
 }
-
-// window sums: one block per (msm, window) adds that window's segment partials (strided loads, LDS tree)
-__global__ void __launch_bounds__(256) k_window_sums(const ge_ext *__restrict__ partial, ge_ext *__restrict__ wsum, uint32_t nseg_per_win) {
-    __shared__ ge_ext lds[256];
-    const ge_ext *P = partial + (size_t)blockIdx.x * nseg_per_win;
-    ge_ext acc = ge_identity();
-    for (uint32_t s = threadIdx.x; s < nseg_per_win; s += 256) acc = ge_add(acc, P[s]);
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d && threadIdx.x + d < nseg_per_win) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
+__device__ __forceinline__ ge_ext ge_dbl_times(ge_ext p, uint32_t k) { for (uint32_t i = 0; i < k; i++) p = ge_dbl(p); return p; }
+__device__ __forceinline__ fe fe_shfl_down(const fe &a, uint32_t d) { fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = __shfl_down(a.v[j], d, 64);
+    return r; }
+__device__ __forceinline__ ge_ext ge_shfl_down(const ge_ext &p, uint32_t d) {
+    ge_ext r; r.X = fe_shfl_down(p.X, d); r.Y = fe_shfl_down(p.Y, d); r.Z = fe_shfl_down(p.Z, d); r.T = fe_shfl_down(p.T, d); return r; }
+// lane l <- sum_{l' >= l} of the wave (lanes >= n hold the identity)
+__device__ __forceinline__ ge_ext ge_wave_suffix(ge_ext s, uint32_t lane, uint32_t n) {
+    for (uint32_t d = 1; d < n; d <<= 1) { const ge_ext o = ge_shfl_down(s, d); if (lane + d < n) s = ge_add(s, o); }
+    return s; }
+// lane 0 <- sum of lanes [0, n), n a power of two
+__device__ __forceinline__ ge_ext ge_wave_sum(ge_ext s, uint32_t lane, uint32_t n) {
+    for (uint32_t d = n >> 1; d > 0; d >>= 1) { const ge_ext o = ge_shfl_down(s, d); if (lane < d) s = ge_add(s, o); }
+    return s; }
+__global__ void __launch_bounds__(512) k_window_sums(const ge_ext *__restrict__ partial, ge_ext *__restrict__ wsum, uint32_t nseg_per_win, uint32_t total,
+                                                     uint32_t lgseg) {
+    __shared__ ge_ext ldsT[8], ldsH[8];
+    const ge_ext *A = partial + (size_t)blockIdx.x * nseg_per_win, *Rn = A + total;
+    const uint32_t nthr = blockDim.x, nw = nthr >> 6, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t per = nseg_per_win > nthr ? nseg_per_win / nthr : 1u, lgper = 31u - (uint32_t)__builtin_clz(per);
+    const uint32_t t0 = threadIdx.x * per;
+    ge_ext Q = ge_identity(), R = ge_identity();
+    if (t0 < nseg_per_win) {
+        // zero-based running sum from the top: Z = sum_j j * run_(t0+j), R = sum run, Q = sum acc
+        ge_ext Z = ge_identity();
+        R = Rn[t0 + per - 1]; Q = A[t0 + per - 1];
+        if (per > 1) Z = R;
+        for (uint32_t k = per - 1; k-- > 0;) {
+            R = ge_add(R, Rn[t0 + k]); Q = ge_add(Q, A[t0 + k]);
+            if (k > 0) Z = ge_add(Z, R);
+        }
+        if (per > 1) Q = ge_add(Q, ge_dbl_times(Z, lgseg));
     }
-    if (threadIdx.x == 0) wsum[blockIdx.x] = lds[0];
+    // suffix sums of R over the block
+    ge_ext S = ge_wave_suffix(R, lane, 64);
+    if (nw > 1) {
+        if (lane == 0) ldsT[wv] = S;
+        __syncthreads();
+        if (wv == 0) {
+            ge_ext Tt = lane < nw ? ldsT[lane] : ge_identity();
+            Tt = ge_wave_suffix(Tt, lane, nw);                            // inclusive; wave w needs the exclusive one: that of w + 1
+            if (lane < nw) ldsH[lane] = Tt;
+        }
+        __syncthreads();
+        if (wv + 1 < nw) S = ge_add(S, ldsH[wv + 1]);
+    }
+    ge_ext X = Q;
+    if (threadIdx.x > 0 && t0 < nseg_per_win) X = ge_add(X, ge_dbl_times(S, lgseg + lgper));
+    X = ge_wave_sum(X, lane, 64);
+    if (nw > 1) {
+        __syncthreads();                                                   // ldsT is reused
+        if (lane == 0) ldsT[wv] = X;
+        __syncthreads();
+        if (wv == 0) { X = lane < nw ? ldsT[lane] : ge_identity(); X = ge_wave_sum(X, lane, nw); }
+    }
+    if (threadIdx.x == 0) wsum[blockIdx.x] = X;
 }
 
 // The recombination of the W window sums, sum_j 2^off(j) * S_j (about 254 dependent doublings of one point), runs on the host

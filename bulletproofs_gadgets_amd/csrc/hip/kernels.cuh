@@ -35,7 +35,13 @@ struct MsmSegs {
 };
 __device__ __forceinline__ uint32_t msm_point_index(const MsmSegs &S, uint32_t seg, uint32_t e) {
     const uint32_t lg = S.lgblk[seg];
+#ifdef BPG_DIAG_INDEX_MASK
+    // DIAGNOSTIC BUILD ONLY (tools/diag/mask_build.sh; never defined for the product): every gathered point index is masked, so the sweep does the
+    // same arithmetic on a table that fits a cache level - wrong sums, same instruction stream - to tell exposed memory time from issue time
+    return (((e >> lg) << (lg + 1)) | (e & ((1u << lg) - 1u))) & (BPG_DIAG_INDEX_MASK);
+#else
     return ((e >> lg) << (lg + 1)) | (e & ((1u << lg) - 1u));
+#endif
 }
 
 }  // namespace bpg

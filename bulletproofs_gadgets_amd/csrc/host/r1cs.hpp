@@ -176,6 +176,9 @@ public:
     // the transcript of the per-call path.  prove(), start_blinding() and commit_precomputed() flush first.
     void defer_commitments(bool on) { if (!on) flush_commitments(); deferred_ = on; }
     void flush_commitments();
+    // TEST HOOK (include/bpg.h bpg_test_prover_stub_commitments): commitments become 32 hash bytes of (v, blinding) made on the host - NOT group
+    // elements - so that the file drivers' parsers and the gadget assembly can be fuzzed under sanitizers without a device; prove() stays refused
+    void test_stub_commitments() { stub_commitments_ = true; }
     size_t num_flushed() const { return flushed_; }
     const uint8_t *commitment(size_t i) const { return &V_[32 * i]; }
 
@@ -257,6 +260,7 @@ private:
     std::vector<Scalar> aL_, aR_, aO_, v_, vb_;
     std::vector<uint8_t> V_;            // the commitments, 32 bytes each (zero until flushed)
     bool deferred_ = false; size_t flushed_ = 0;
+    bool stub_commitments_ = false;
     int64_t pending_ = -1;
 };
 

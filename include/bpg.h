@@ -71,6 +71,8 @@ typedef struct {
 
 typedef struct {                  /* milliseconds; filled when a non-NULL pointer is passed to a prove call */
     double rng_host, msm_aiao, msm_s, poly, ipa, total, ipa_msm, ipa_fold, ipa_sync;
+    double shared_variants;       /* 1.0: the proof took the kernel variants for a shared device (another prove() was in flight on the device when this one
+                                     was entered; decided once per proof) - replay a failing proof with BPG_FOLD_ADAPT=2 (always) or 0 (never) */
 } bpg_timings;
 
 /* ---------------------------------------------------------------------------------------------------- PART 1: hot path */
@@ -80,7 +82,7 @@ const char *bpg_last_error(void);                                /* message of t
 /* replaces PedersenGens::default() + device selection            (reference src/bin/prover.rs:53).
  * bpg_ctx_create(device, out) = bpg_ctx_create_ex(device, NULL, out): the ONE-SHOT profile - what a process that proves once and exits wants
  * (the reference's prover binary, src/bin/prover.rs:47-100): at most 4 GB of precomputed tables beside the generators (3.0 GB at 2^20, 7 ms).
- * bpg_ctx_create_ex takes the choices a host has: a zeroed bpg_config with struct_size set means "defaults"; a field left at 0 / -1 / NULL falls
+ * bpg_ctx_create_ex takes the choices a host has: a zeroed bpg_config with struct_size set means "defaults"; a field left at 0 / NULL falls
  * back to the environment variable named beside it, then to the profile's default.  Every setting gives the same proof bytes. */
 #define BPG_PROFILE_DEFAULT 0u   /* BPG_PROFILE=oneshot|serving if set, else one-shot */
 #define BPG_PROFILE_ONESHOT 1u   /* first generator fold on width-6 NAF tables of whole scalars; no 8-bit tail tables; table budget 4 GB */
@@ -94,8 +96,9 @@ typedef struct {
                                     not fit is replaced by the next smaller table set, in the end by kernels that need none; 0 = profile default */
     uint32_t chain_workers;      /* bpg_ctx_set_chain_workers at creation (BPG_CHAIN_WORKERS); 0 = default 1 */
     uint32_t chain_lanes;        /* bpg_ctx_set_chain_lanes at creation (BPG_CHAIN_LANES); 0 = default 1 */
-    int32_t blocking_sync;       /* 1: host threads sleep in stream waits (hipDeviceScheduleBlockingSync; device-wide, first context of the process
-                                    decides) - for hosts that run many proving threads beside their chain threads; 0 spin; -1 = BPG_SYNC_BLOCKING, else 0 */
+    uint32_t blocking_sync;      /* 1: host threads sleep in stream waits (hipDeviceScheduleBlockingSync; device-wide, first context of the process
+                                    decides) - for hosts that run many proving threads beside their chain threads; 2: spin; 0 = BPG_SYNC_BLOCKING
+                                    (1 / 0) if set, else spin */
     const char *gens_cache_dir;  /* directory of the on-disk generator cache (BPG_GENS_CACHE_DIR); NULL = no cache */
 } bpg_config;
 int32_t bpg_device_count(void);          /* AMD GPUs visible to the process (0: none - every bpg_ctx_create then fails with BPG_ERR_DEVICE) */
@@ -191,6 +194,10 @@ bpg_status bpg_transcript_state(const bpg_transcript *t, uint8_t out[BPG_TRANSCR
 
 bpg_status bpg_prover_new(bpg_ctx *ctx, bpg_transcript *t, bpg_prover **out);                   /* Prover::new */
 void bpg_prover_free(bpg_prover *p);
+/* test hook: from now on the commitments of p are 32 hash bytes of (value, blinding) made on the host - NOT group elements - so that a device-less
+ * prover (bpg_prover_new with ctx = NULL) can run a file driver's parsing and gadget assembly under sanitizers / a fuzzer; bpg_prover_prove stays
+ * refused (BPG_ERR_DEVICE) */
+bpg_status bpg_test_prover_stub_commitments(bpg_prover *p);
 bpg_status bpg_prover_commit(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], uint8_t com_out[32], uint32_t *var_out);
 bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, const uint8_t *blind, uint8_t *coms_out, uint32_t *vars_out);
 /* Prover::commit for a host that computes its Pedersen commitments elsewhere (its own PedersenGens, or a prover created without a device

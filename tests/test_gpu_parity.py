@@ -176,6 +176,34 @@ def test_msm_with_wide_windows_on_small_sums(cmin, monkeypatch):
         c.close()
 
 
+@pytest.mark.parametrize("env", [{"BPG_RSEG": "1"}, {"BPG_RSEG": "2"}, {"BPG_RSEG": "64"}, {"BPG_RSEG": "1024"}, {"BPG_LGCH": "2"}, {"BPG_LGCH": "7"},
+                                 {"BPG_SWEEP_RESIDENT": "64"}, {"BPG_SWEEP_RESIDENT": "4096", "BPG_FOLD_ADAPT": "2"}, {"BPG_FOLD_ADAPT": "2", "BPG_RSEG": "16"},
+                                 {"BPG_FOLD_ADAPT": "0", "BPG_MSM_CMAX": "12"}])
+def test_msm_epilogue_and_sweep_knobs_give_the_oracle_sum(env, monkeypatch):
+    """The diagnostic knobs of the bucket-method MSM - BPG_RSEG (buckets per thread of the first level of the window epilogue), BPG_LGCH (chunk
+    length of the sweep), BPG_SWEEP_RESIDENT (blocks the device is taken to hold), BPG_FOLD_ADAPT = 2 (the shared-device variants: 16-bit windows,
+    64-entry chunks, 256-thread window blocks) - change how the sum is scheduled, never its value: windows from 2 to 16 bits wide, with and
+    without whole empty segments, identical scalars in one bucket, against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for cmin in ("2", "11", "16"):
+        monkeypatch.setenv("BPG_MSM_CMIN", cmin)
+        c = bpg.Context(0)
+        try:
+            c.gens_ensure(8192)
+            for count in (1, 70, 3000):
+                G, Hh = c.gens_export(3, count)
+                s = [rs(b"ks", i) for i in range(count)]
+                t = [rs(b"kt", i) for i in range(count)]
+                for i in range(0, count, 3):
+                    t[i] = sc(R.L - 2)                          # a third of the terms in ONE bucket of every window
+                for i in range(1, count, 11):
+                    s[i] = bytes(32)
+                assert c.msm_gens(3, s, t) == O.msm(b"".join(s + t), G + Hh, 1), (env, cmin, count)
+        finally:
+            c.close()
+
+
 def test_deferred_commitments_equal_one_launch_per_commitment(ctx):
     """bpg_prover_defer_commitments (batched witness commitment): the variables are registered at once, the commitments come
     from ONE k_pedersen launch at the flush and enter the transcript in commit order - same commitments, same transcript, same proof as the

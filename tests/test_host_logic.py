@@ -394,3 +394,27 @@ def test_config_struct_matches_the_header_and_pool_api_without_a_gpu(tmp_path):
     with pytest.raises(bpg.BpgError) as e:
         bpg.Context(0, profile=2, chain_lanes=9)
     assert e.value.status in (4, 7)
+
+
+@pytest.mark.parametrize("var,val", [("BPG_RSEG", "0"), ("BPG_RSEG", "3"), ("BPG_RSEG", "abc"), ("BPG_RSEG", "2048"), ("BPG_RSEG", "8x"), ("BPG_LGCH", "1"), ("BPG_LGCH", "zz"),
+                                     ("BPG_SWEEP_RESIDENT", "0"), ("BPG_MSM_CMAX", "17"), ("BPG_MSM_CMIN", ""), ("BPG_FOLD_GROUP", "6"), ("BPG_FOLD_WNAF", "2"),
+                                     ("BPG_FOLD_PARTS", "3"), ("BPG_TT_LG", "-1"), ("BPG_TABLE_GB", "-4"), ("BPG_FOLD_TABLE_GB", "nan"), ("BPG_CHAIN_LANES", "9"),
+                                     ("BPG_SYNC_BLOCKING", "2"), ("BPG_FOLD_ADAPT", "3")])
+def test_bad_environment_knobs_are_refused_at_context_creation(var, val, monkeypatch):
+    """Every BPG_* knob is read once, when the context is created, BEFORE the device is touched: a value that does not parse or is out of range is
+    BPG_ERR_INVALID_ARGUMENT from bpg_ctx_create - with or without a GPU - never a silent default and never a fault on the hot path (round 3 read
+    BPG_RSEG with atoi on every MSM call and divided by it: SIGFPE across the C ABI).  An EMPTY variable counts as unset."""
+    monkeypatch.setenv(var, val)
+    import torch
+    if val == "":
+        if torch.cuda.is_available():
+            bpg.Context(0).close()
+        else:
+            with pytest.raises(bpg.BpgError) as e:
+                bpg.Context(0)
+            assert e.value.status == 7
+        return
+    with pytest.raises(bpg.BpgError) as e:
+        bpg.Context(0)
+    assert e.value.status == 4, (var, val, e.value.status, str(e.value))
+    assert var in str(e.value)
