@@ -378,12 +378,24 @@ def one_shot_leg(args):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BPG_PROFILE"):
         env.pop(k, None)
+    parent_gb = None
+    try:
+        import torch
+        free_b, total_b = torch.cuda.mem_get_info(0)
+        parent_gb = (total_b - free_b) / 1e9                    # what THIS process still holds on the card (serving tables, one stream's workspace)
+    except Exception:       # noqa: BLE001
+        pass
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": "one-shot leg failed (rc %d): %s" % (r.returncode, r.stderr[-600:])}
     d = json.loads(lines[-1])
-    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "hbm_in_use": d.get("hbm_in_use"),
+    hbm = d.get("hbm_in_use")
+    if hbm and parent_gb is not None:
+        hbm = dict(hbm, in_use_GB=hbm["in_use_GB"] - parent_gb, device_in_use_GB=hbm["in_use_GB"], parent_process_GB=parent_gb,
+                   note="device memory the one-shot child process holds with all its proving streams alive = what the card reports in use minus what the "
+                        "parent (this serving run, idle meanwhile) held when it started the child")
+    return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "hbm_in_use": hbm,
             "completions": d.get("completions"), "schedule": d.get("schedule"), "busy_cores_avg": d["config"]["host_threads_per_gpu"]["busy_cores_avg"],
             "note": "the same timed steps with every engine context under the one-shot profile (bpg_ctx_create's default; blocking stream waits as in the headline), "
                     "in a child process of this run while this process idles; `value` of the line is the serving profile"}

@@ -32,7 +32,7 @@ def build_cli(verbose=False):
     if all(b.exists() and b.stat().st_mtime >= max(CLI_SRC.stat().st_mtime, LIB.stat().st_mtime) for b in CLI_BINS):
         return CLI_BINS
     CLI_BINS[0].parent.mkdir(exist_ok=True)
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-pthread", str(CLI_SRC), "-o", str(CLI_BINS[0]), "-L", str(PKG), "-lbpg_hip",
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-g", "-rdynamic", "-std=c++17", "-pthread", str(CLI_SRC), "-o", str(CLI_BINS[0]), "-L", str(PKG), "-lbpg_hip",
            "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd))

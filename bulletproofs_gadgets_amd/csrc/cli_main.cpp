@@ -32,6 +32,8 @@
 #include <atomic>
 #include <mutex>
 #include <thread>
+#include <execinfo.h>
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 #include "../../include/bpg.h"
@@ -709,7 +711,16 @@ int run_batch(const std::string &self_path, const std::string &mode, const std::
 }  // namespace
 
 #ifndef BPG_CLI_NO_MAIN
+// a crash must not be silent: the frames go to stderr (async-signal-safe calls only), then the default action takes over
+static void crash_report(int sig) {
+    static const char msg[] = "bpg_prover/bpg_verifier: fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    void *frames[48];
+    backtrace_symbols_fd(frames, backtrace(frames, 48), 2);
+    signal(sig, SIG_DFL); raise(sig);
+}
 int main(int argc, char **argv) {
+    for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) signal(sig, crash_report);
     std::string self = argv[0]; size_t slash = self.rfind('/'); if (slash != std::string::npos) self = self.substr(slash + 1);
     std::string mode, name;
     {   // --batch FILE [--gpus N]   (and, for the ranks the command starts itself: --rank R --world N, results on descriptor 3)

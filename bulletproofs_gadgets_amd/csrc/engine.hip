@@ -200,7 +200,7 @@ struct DeviceCircuit {
 
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
-    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) X(k_scale2) \
+    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
@@ -243,7 +243,7 @@ struct Engine::Impl {
     DevBuf gens;                                // view of shared->gens (not owned)
     DevBuf bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, open_keys, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
     uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 4 per CU of the device the context is created on (BPG_SWEEP_RESIDENT overrides)
     uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps)
     uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (digits are 16-bit)
@@ -582,7 +582,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
@@ -903,21 +903,26 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
     }
     {
-        slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext));
+        slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext)); open_keys.ensure((size_t)nchunks * 4);
         ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
         BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(),
-                   buckets.as<ge_ext>(), slotA, slotB, nkeys, CH);
+                   buckets.as<ge_ext>(), slotA, slotB, open_keys.as<uint32_t>(), nkeys, CH);
         // roofline bookkeeping.  Algorithmic bytes: the information content of the MSM this launch sweeps, one scalar + one
         // point = 64 B per TERM, counted once however many windows the term is cut into.  Device bytes: every (term, window) entry is a
         // 4-byte index and a 96-byte affine Niels point.  Work: one mixed addition (7 field multiplications) per entry; Mub counts zero
         // digits too (probability 2^-c each for full-width scalars).
         prof_note(KID_k_bucket_chunks, 64.0 * (double)total, 100.0 * (double)Mub, 7.0 * (double)Mub);
-        BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, CH, heavy.as<uint32_t>());
+        // joining the pieces of buckets that cross chunk boundaries: one thread per boundary where chunks are at least as long as the average bucket
+        // (the shared-device shape: 64-entry chunks, ~32 entries per bucket), one thread per bucket where buckets are longer (a proof alone)
+        if ((uint64_t)CH * nkeys >= Mub)
+            BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nchunks, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, open_keys.as<uint32_t>(), nkeys, CH, heavy.as<uint32_t>());
+        else
+            BPG_LAUNCH_ID((*this), KID_k_bucket_combine, k_bucket_combine_per_bucket, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, CH, heavy.as<uint32_t>());
         BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, CH, heavy.as<uint32_t>());
     }
     const uint32_t nred = nmsm * W * nsegpw;
-    BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
+    BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), starts.as<uint32_t>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
     wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
     // a window's block: as many threads as it has segments, at most 512 for a proof alone (shortest chain) and 256 while the device is shared (fewest additions)
     const uint32_t wthreads = std::max<uint32_t>(64, std::min<uint32_t>(nsegpw, shared_now ? 256u : 512u));
@@ -1144,8 +1149,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
         I.red_partial.ensure((size_t)blocks * 2 * sizeof(scm) + 4096);
         BPG_LAUNCH(I, k_ipa_prep, dim3(blocks), dim3(256), a, b, I.yinvpow.as<scm>(), c0, c0 + GRP_STRIDE, uch_m,
                            (uint32_t)g_first, (uint32_t)n, lgh, g_j, sLG, sLH, sRG, sRH, I.red_partial.as<scm>());
-        BPG_LAUNCH(I, k_reduce_partials, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3);
-        BPG_LAUNCH(I, k_scale2, dim3(1), dim3(64), I.extras.as<scm>() + 3, w_m);
+        BPG_LAUNCH_ID(I, KID_k_reduce_partials, k_reduce_partials_scaled, dim3(2), dim3(256), I.red_partial.as<scm>(), blocks, 2u, I.extras.as<scm>() + 3, w_m);
         Impl::MsmTicket tk;
         {
             MsmSegs S = seg_new();
@@ -1481,6 +1485,23 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         // host draws the next one (the copies queue behind the A_I/A_O kernels on the stream and overlap the serial chain)
         uint8_t *raw = bs ? bs->raw : I.h_raw.as<uint8_t>();
         const uint64_t slab = 1u << 16;
+        if (bs && chain_ready && 2 * n > 0) {
+            // the whole chain was drawn (and handed to the copy stream) before this proof started - a sequence of proofs with its chains drawn
+            // ahead: wait for every block's event, then ONE conversion launch instead of one per 4 MB block (31 at 2^20)
+            const uint64_t nblk = (2 * n + Impl::BlindStream::UP - 1) / Impl::BlindStream::UP;
+            while (bs->uploaded_blocks.load(std::memory_order_acquire) < nblk) {
+                if (bs->finished.load(std::memory_order_acquire) && bs->uploaded_blocks.load(std::memory_order_acquire) < nblk) break;     // stopped short: handled below
+                std::this_thread::sleep_for(std::chrono::microseconds(40));
+            }
+            if (const int uerr = bs->err.load(std::memory_order_acquire)) {
+                Impl::blind_stop(bs);
+                for (auto it = I.blinds.begin(); it != I.blinds.end(); ++it) if (it->get() == bs.get()) { I.blinds.erase(it); break; }
+                throw DeviceError(std::string("upload of the blinding draws failed: ") + hipGetErrorString((hipError_t)uerr));
+            }
+            if (bs->uploaded_blocks.load(std::memory_order_acquire) < nblk) throw DeviceError("the blinding stream ended before its draws were uploaded");
+            for (uint64_t k = 0; k < nblk; k++) HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
+            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw), sL, (uint32_t)(2 * n));
+        } else
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
             if (bs) {

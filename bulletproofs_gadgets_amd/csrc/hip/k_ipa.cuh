@@ -41,8 +41,7 @@ __global__ void __launch_bounds__(256) k_ipa_prep(const scm *__restrict__ a, con
     r = block_sum_256(cR, lds); if (threadIdx.x == 0) partial[blockIdx.x * 2 + 1] = r;
 }
 __global__ void k_set2(scm *__restrict__ c, uint32_t stride, scm v0, scm v1) { if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = v0; c[stride] = v1; } }
-// c[k] *= w   (k < 2): the Q = w*B term of L and R becomes a scalar on the fixed base B
-__global__ void k_scale2(scm *__restrict__ c, scm w) { if (threadIdx.x < 2 && blockIdx.x == 0) c[threadIdx.x] = sc_mont_mul(c[threadIdx.x], w); }
+// (the Q = w*B term of L and R becomes a scalar on the fixed base B: c_L * w, c_R * w come out of k_reduce_partials_scaled, k_scalars.cuh)
 
 __global__ void __launch_bounds__(256) k_ipa_fold_scalars(scm *__restrict__ a, scm *__restrict__ b, scm u, scm uinv, uint32_t h) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

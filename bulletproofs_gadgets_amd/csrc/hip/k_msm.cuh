@@ -277,6 +277,7 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
 // goes on) for k_bucket_combine.  CH is any length (not a power of two): the host picks it so that the blocks of a launch fill the CUs
 // a whole number of times (engine.hip Impl::msm) - with 2^5 entries per chunk the 4,352 blocks of a 2^21-term launch were 4.25 rounds of the
 // 1,024 blocks the device holds, and the last quarter round ran on a quarter of the machine.
+#define MSM_NO_KEY 0xffffffffu
 // bucket that holds sorted entry e: the k >= klo with starts[k] <= e < starts[k+1]  (upper_bound - 1)
 __device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ starts, uint32_t nkeys, uint32_t e, uint32_t klo) {
     uint32_t lo = klo, hi = nkeys + 1;
@@ -297,6 +298,7 @@ __device__ __forceinline__ ge_ext ge_madd_swapped(const ge_ext &p, const fe &qp,
 }
 __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
                                                        ge_ext *__restrict__ buckets, ge_ext *__restrict__ slotA, ge_ext *__restrict__ slotB,
+                                                       uint32_t *__restrict__ open_key /* [chunk]: bucket whose first piece is slotB[chunk], or MSM_NO_KEY */,
                                                        uint32_t nkeys, uint32_t CH) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t e0w = (uint64_t)c * CH;
@@ -326,24 +328,49 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
         }
         acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
     }
+    uint32_t open = MSM_NO_KEY;
     if (kstart >= e0 && kend <= e1) buckets[k] = acc;
     else if (kstart < e0) slotA[c] = acc;                    // a bucket that began earlier (and may go on beyond this chunk)
-    else slotB[c] = acc;                                     // begins here and goes on
+    else { slotB[c] = acc; open = k; }                       // begins here and goes on: k_bucket_combine's thread c joins its pieces
+    open_key[c] = open;
 }
 
-// one thread per bucket: identity for empty buckets, nothing for single-chunk buckets, slotB[c0] + slotA[c0+1..c1] for a
-// bucket spread over a few chunks; a bucket spread over more than HEAVY_CHUNKS chunks (thousands of identical scalars: the
-// -y^h padding terms of the first IPA round, repeated witness values) goes on the heavy list for k_bucket_combine_heavy
+// Joining the pieces of the buckets that cross chunk boundaries.  One thread per CHUNK BOUNDARY (round 4; rounds 1-3 ran one thread per bucket,
+// and since a wave executes the addition as soon as one of its lanes needs it, a million mostly idle bucket threads issued 2.5x the additions
+// that were needed): thread c looks at the bucket that holds the LAST entry of chunk c.  If that bucket began in chunk c and goes on beyond it,
+// the thread owns it (the sweep leaves the bucket's key in open_key[c]): slotB[c] + slotA[c+1 .. c1].  A bucket that began earlier belongs to the thread of the chunk it began in; a bucket that
+// ends with the chunk needs nothing.  With 64-entry chunks and ~32 entries per bucket nearly every boundary is crossed by exactly one bucket:
+// every lane does one addition.  A bucket spread over more than HEAVY_CHUNKS chunks (thousands of identical scalars: the -y^h padding terms of
+// the first IPA round, repeated witness values) goes on the heavy list for k_bucket_combine_heavy.  Empty buckets are never written: the
+// epilogue (k_bucket_reduce) takes the identity for a bucket whose range is empty.
 #define HEAVY_CHUNKS 32
 __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                         const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
-                                                        uint32_t nkeys, uint32_t CH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
+                                                        const uint32_t *__restrict__ open_key, uint32_t nkeys, uint32_t CH,
+                                                        uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t M = starts[nkeys];
+    if ((uint64_t)c * CH >= M) return;                           // the sweep had no such chunk (open_key[c] was not written)
+    const uint32_t k = open_key[c];                              // the bucket that began in chunk c and goes on beyond it, as the sweep saw it
+    if (k == MSM_NO_KEY) return;
+    const uint32_t c1 = (starts[k + 1] - 1) / CH;
+    if (c1 - c > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
+    ge_ext acc = slotB[c];
+    for (uint32_t cc = c + 1; cc <= c1; cc++) acc = ge_add(acc, slotA[cc]);
+    buckets[k] = acc;
+}
+// The same join with one thread per BUCKET: the better shape when buckets are longer than chunks (a proof alone on the device: 15-bit windows, 64
+// entries per bucket, 34-entry chunks - every bucket crosses two or three boundaries, so every lane has its two additions, while two of three
+// boundary threads would idle).  The host picks by the average bucket length (engine.hip Impl::msm).
+__global__ void __launch_bounds__(256) k_bucket_combine_per_bucket(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
+                                                                   const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
+                                                                   uint32_t nkeys, uint32_t CH, uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nkeys) return;
     const uint32_t s0 = starts[k], s1 = starts[k + 1];
-    if (s0 == s1) { buckets[k] = ge_identity(); return; }
+    if (s0 == s1) return;                                        // empty: never read (k_bucket_reduce takes the identity)
     const uint32_t c0 = s0 / CH, c1 = (s1 - 1) / CH;
-    if (c0 == c1) return;
+    if (c0 == c1) return;                                        // inside one chunk: the sweep stored it
     if (c1 - c0 > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
     ge_ext acc = slotB[c0];
     for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
@@ -382,15 +409,22 @@ __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__
 //                    thread: Q = sum acc_t + seg * sum_j j * run_t (running sums again, 3 additions per segment), R = sum run_t;
 //                    sum_tau tau * R_tau = sum_{tau >= 1} Suf_tau with Suf_tau = sum_{tau' >= tau} R_tau' - a suffix scan over the block
 //                    (wave shuffles, then the wave totals through LDS) instead of multiplications by tau; S = sum_tau (Q_tau + seg*per*Suf_tau).
-__global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__ buckets, ge_ext *__restrict__ partial,
+__global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__ buckets, const uint32_t *__restrict__ starts, ge_ext *__restrict__ partial,
                                                      uint32_t nb, uint32_t seg, uint32_t nseg_per_win, uint32_t total) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     uint32_t win = t / nseg_per_win, sg = t % nseg_per_win;
     uint32_t lo = sg * seg;
     const ge_ext *B = buckets + (size_t)win * nb;
-    ge_ext run = B[lo + seg - 1], acc = run;
-    for (int32_t b = (int32_t)(lo + seg) - 2; b >= (int32_t)lo; b--) { run = ge_add(run, B[b]); acc = ge_add(acc, run); }
+    const uint32_t *S = starts + (size_t)win * nb;                 // bucket b of this window holds entries [S[b], S[b+1]): empty -> the identity, B[b] was never written
+    uint32_t hi = S[lo + seg];
+    uint32_t cur = S[lo + seg - 1];
+    ge_ext run = cur != hi ? B[lo + seg - 1] : ge_identity(), acc = run;
+    for (int32_t b = (int32_t)(lo + seg) - 2; b >= (int32_t)lo; b--) {
+        hi = cur; cur = S[b];
+        if (cur != hi) run = ge_add(run, B[b]);
+        acc = ge_add(acc, run);
+    }
     partial[t] = acc; partial[(size_t)total + t] = run;
 }
 __device__ __forceinline__ ge_ext ge_dbl_times(ge_ext p, uint32_t k) { for (uint32_t i = 0; i < k; i++) p = ge_dbl(p); return p; }

@@ -107,6 +107,15 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const scm *__restrict__
     scm r = block_sum_256(acc, lds);
     if (threadIdx.x == 0) out[k] = r;
 }
+// the same with every sum multiplied by w (the c_L * w, c_R * w scalars of Q = w * B in an inner-product round: one launch instead of two)
+__global__ void __launch_bounds__(256) k_reduce_partials_scaled(const scm *__restrict__ partial, uint32_t parts, uint32_t stride, scm *__restrict__ out, scm w) {
+    __shared__ scm lds[256];
+    uint32_t k = blockIdx.x;
+    scm acc = sc_zero();
+    for (uint32_t p = threadIdx.x; p < parts; p += 256) acc = sc_add(acc, partial[(size_t)p * stride + k]);
+    scm r = block_sum_256(acc, lds);
+    if (threadIdx.x == 0) out[k] = sc_mont_mul(r, w);
+}
 
 // ------------------------------------------------------------------------------------------------ circuit upload: CSR -> CSC on the device
 // The caller's constraint list is row-major (one row per constraint); k_flatten wants it column-major (one column per variable).

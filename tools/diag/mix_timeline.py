@@ -13,7 +13,7 @@ rows = []
 with open(sys.argv[1]) as f:
     for x in csv.DictReader(f):
         name = x["Kernel_Name"].split("(")[0].replace("bpg::", "").replace("void ", "")
-        stream = x.get("Stream_Id") or x.get("Queue_Id") or "0"
+        stream = x.get("Thread_Id") or x.get("Stream_Id") or "0"     # one proving thread per HIP stream: the launching thread identifies the stream
         rows.append((int(x["Start_Timestamp"]), int(x["End_Timestamp"]), name, stream))
 rows.sort()
 win = float(sys.argv[2]) * 1e9 if len(sys.argv) > 2 else 2.0e9
