@@ -639,7 +639,8 @@ def run_rank(args):
     chain_cpu = ctx.chain_cpu()
     ranks_seen = gather_objects({"rank": rank, "device": device_index, "pci": placement.get("pci"), "numa_node": placement.get("numa_node"),
                                  "cpus_allowed": placement.get("cpus_allowed"), "chain_cpu": chain_cpu, "main_cpu": current_cpu(),
-                                 "ms_per_step": elapsed_local / args.steps * 1e3})
+                                 "ms_per_step": elapsed_local / args.steps * 1e3, "proving_streams": n_streams, "chain_pool_lanes": pool_lanes if pool is not None else None,
+                                 "hbm_in_use_GB": hbm_used["in_use_GB"] if hbm_used else None})      # the DEVICE's figure: ranks that share a card (gloo rehearsal) see the sum
     last = outs[-1]
 
     # ---- strong-scaling leg: a fixed batch of independent proofs, sharded round-robin over the ranks (north_star: 8 proofs, >= 6x at 8 GPUs)

@@ -421,7 +421,7 @@ struct ProverRun {
         }
         lap("gadget assembly");
         out_constraints = bpg_prover_num_constraints(p);
-        if (!quiet) std::printf("%llu\n", (unsigned long long)out_constraints);          // prover.rs:89
+        if (!quiet) { std::printf("%llu\n", (unsigned long long)out_constraints); std::fflush(stdout); }          // prover.rs:89
         const uint64_t n = bpg_prover_num_multiplications(p), cap = round_pow2(n);
         if (assemble_only) { out_proof_len = 0; return 0; }
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
@@ -560,8 +560,9 @@ struct VerifierRun {
         chk(bpg_gens_ensure(ctx, cap), "BulletproofGens::new");
         Bytes seed(32); { std::ifstream r("/dev/urandom", std::ios::binary); r.read(reinterpret_cast<char *>(seed.data()), 32); }
         const bpg_status s = bpg_verifier_verify(v, ctx, cap, proof.data(), proof.size(), seed.data(), 0);
-        if (s == BPG_OK) { if (!quiet) std::puts("true"); return 0; }                 // verifier.rs:91-100
-        if (s == BPG_ERR_VERIFICATION || s == BPG_ERR_FORMAT) { if (!quiet) std::puts("false"); return 1; }
+        // (flushed at once: the verdict must reach the caller whatever happens while the process winds down)
+        if (s == BPG_OK) { if (!quiet) { std::puts("true"); std::fflush(stdout); } return 0; }                 // verifier.rs:91-100
+        if (s == BPG_ERR_VERIFICATION || s == BPG_ERR_FORMAT) { if (!quiet) { std::puts("false"); std::fflush(stdout); } return 1; }
         fail(std::string("Verifier::verify: ") + (bpg_last_error() ? bpg_last_error() : "error"));
     }
     ~VerifierRun() { if (v) bpg_verifier_free(v); if (tr) bpg_transcript_free(tr); if (ctx && own_ctx) bpg_ctx_destroy(ctx); }

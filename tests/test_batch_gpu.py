@@ -95,21 +95,28 @@ def test_two_processes_one_gpu_gather_real_proofs(tmp_path):
     assert "rank 0 ok" in r.stdout and "rank 1 ok" in r.stdout
 
 
-def test_bench_spawns_its_own_ranks():
-    """python bench.py --gpus 2 without torchrun: the launcher starts two fresh ranks (gloo rehearsal on the one card) and relays ONE line."""
+@pytest.mark.parametrize("leaves,steps", [(8, 2), (512, 4)])
+def test_bench_spawns_its_own_ranks(leaves, steps):
+    """python bench.py --gpus 2 without torchrun: the launcher starts two fresh ranks (gloo rehearsal on the one card) and relays ONE line - at the
+    small size and at the HEADLINE size (512 leaves: two ranks with their own serving tables and proving streams on one card; the line carries
+    each rank's view of the card's memory)."""
     env = dict(os.environ, BPG_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--leaves", "8", "--batch", "4",
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1", "--leaves", str(leaves), "--batch", "4",
                         "--no-cpu-baseline", "--in-flight", "2", "--in-flight-steps", "4"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["n_gpus"] == 2 and out["steps"] == steps and out["scaling"] == "weak"
+    assert all(x["hbm_in_use_GB"] and x["hbm_in_use_GB"] > 0 for x in out["ranks_seen"])
+    if leaves == 512:
+        assert out["config"]["N"] == 1 << 20 and out["config"]["q"] == 1986769
+        print("two ranks at 2^20 on one card: %s" % [(x["rank"], x["proving_streams"], round(x["hbm_in_use_GB"], 1)) for x in out["ranks_seen"]])
     assert sorted(x["rank"] for x in out["ranks_seen"]) == [0, 1]
     assert out["batch"]["proofs"] == 4 and out["batch"]["ranks"] == 2 and out["batch"]["proofs_per_rank"] == 2
-    assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0
+    assert out["value"] > 0 and out["roofline"]["whole_proof"]["alg_bytes"] > 0 and out["schedule"]["tt_lg"] == 12
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):       # the roofline object of the driver contract
         assert key in out["roofline"], key
     assert out["unit"] == "constraints/s" and out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "u32"

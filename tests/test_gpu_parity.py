@@ -772,6 +772,34 @@ def test_speculative_blinding_stream_changes_no_byte(ctx):
         assert rc == 0 and a == want
 
 
+def test_chain_knobs_from_the_environment_change_no_byte(monkeypatch):
+    """BPG_CHAIN_WORKERS / BPG_CHAIN_LANES / BPG_SYNC_BLOCKING (the environment fall-backs of bpg_config.chain_workers / chain_lanes / blocking_sync, read
+    when the context is created): two chain threads with two lockstep lanes each and blocking stream waits draw the queued chains of a sequence of
+    proofs; every proof equals the one made without any stream."""
+    monkeypatch.setenv("BPG_CHAIN_WORKERS", "2")
+    monkeypatch.setenv("BPG_CHAIN_LANES", "2")
+    monkeypatch.setenv("BPG_SYNC_BLOCKING", "1")
+    c = bpg.Context(0)
+    plain = bpg.Context(0, chain_workers=1, chain_lanes=1, blocking_sync=False)
+    try:
+        a = workloads.mimc_preimage(c, nbytes=300, seed=9, label=b"MiMCHash")        # 10 blocks: n = 9,720, N = 2^14: the draws cross two snapshots
+        inst, state = a.prover.instance(), a.transcript.state
+        for x in (c, plain):
+            x.gens_ensure(a.gens_capacity)
+        res, ref = c.upload(inst), plain.upload(inst)
+        seeds = [bytes([k + 3]) * 32 for k in range(5)]
+        want = [ref.prove(state, inst.v_blinding, s, 0)[0] for s in seeds]
+        for s in seeds:                                              # workers * lanes + 1 = 5 streams may be alive
+            c.blinding_begin(state, inst.v_blinding, s, inst.n)
+        got = [res.prove(state, inst.v_blinding, s, 0)[0] for s in seeds]
+        assert got == want
+        rc, oracle, _ = O.prove(O.Gens(a.gens_capacity), state, to_oracle(inst), inst.v_blinding, seeds[0], O.FLAG_FAST_MSM)
+        assert rc == 0 and got[0] == oracle
+        res.free(); ref.free()
+    finally:
+        c.close(); plain.close()
+
+
 def test_queued_blinding_streams_serve_a_sequence_of_proofs(ctx):
     """The chain worker draws queued streams one at a time, in order; up to two stay alive (one proving stream's sequence: begin(i+1), prove(i)).
     Every proof of the sequence equals the stand-alone proof of the same seed; a third begin retires the oldest stream; proofs whose

@@ -353,6 +353,13 @@ def test_host_thread_planning_on_synthetic_topologies():
     assert bench.cores_for_rank(128, 1, quota=16) == 16
     # plenty of cores: one lane per stream, never more threads than streams
     assert bench.plan_chain_pool(64, 20) == [1] * 20 and bench.plan_chain_pool(64, 3) == [1] * 3
+    # the 8-GPU node of BASELINE config 5 with 128 cores in all (profiles/r04_appetite.txt: which row of the appetite table it can host): 16 cores per
+    # rank -> 14 chain threads per rank, 112 on the node - the 20-stream row of one GPU, on every GPU at once; with 10 streams per rank every chain has
+    # a core to itself (10 threads per rank, 80 on the node), with 6 streams 48
+    assert bench.cores_for_rank(64, 4) * 8 == 128
+    assert [len(bench.plan_chain_pool(16, n)) for n in (20, 10, 6)] == [14, 10, 6]
+    assert [sum(bench.plan_chain_pool(16, n)) for n in (20, 10, 6)] == [20, 10, 6]
+    assert 8 * len(bench.plan_chain_pool(16, 20)) == 112 and 8 * (len(bench.plan_chain_pool(16, 20)) + 2) <= 128
     for cores in range(1, 40):
         for n in (1, 2, 3, 8, 14, 20, 33):
             lanes = bench.plan_chain_pool(cores, n)

@@ -13,7 +13,18 @@ template <int V> __global__ void __launch_bounds__(256) kb(uint32_t *out, uint32
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t a = t * 2654435761u + 1, b = t ^ 0x9e3779b9u, c = t + 77, d = ~t;
     uint64_t p = t, q = t + 1, r = t + 2, s = t + 3, cc; uint32_t c2 = t, e0 = t * 3, e1 = t * 5;
+    double fp = 1.0 + t * 1e-9, fq = 1.5 + t * 1e-9, fr = 0.5 + t * 1e-9, fs = 0.25 + t * 1e-9; const double fa = 1.0000001, fb = 1e-30;
+    float gp = 1.0f + t * 1e-6f, gq = 1.5f, gr = 0.5f, gs = 0.25f; const float ga = 1.0001f, gb = 1e-20f;
     for (uint32_t i = 0; i < iters; i++) {
+        // floating-point candidates for a limb product (round 4): is a double-precision FMA cheaper to issue than v_mad_u64_u32?
+        if (V == 21) { REP16(asm volatile("v_fma_f64 %0, %0, %4, %5\n\tv_fma_f64 %1, %1, %4, %5\n\tv_fma_f64 %2, %2, %4, %5\n\tv_fma_f64 %3, %3, %4, %5"
+                                           : "+v"(fp), "+v"(fq), "+v"(fr), "+v"(fs) : "v"(fa), "v"(fb));) }
+        if (V == 22) { REP16(asm volatile("v_add_f64 %0, %0, %4\n\tv_add_f64 %1, %1, %4\n\tv_add_f64 %2, %2, %4\n\tv_add_f64 %3, %3, %4"
+                                           : "+v"(fp), "+v"(fq), "+v"(fr), "+v"(fs) : "v"(fb));) }
+        if (V == 23) { REP16(asm volatile("v_fma_f32 %0, %0, %4, %5\n\tv_fma_f32 %1, %1, %4, %5\n\tv_fma_f32 %2, %2, %4, %5\n\tv_fma_f32 %3, %3, %4, %5"
+                                           : "+v"(gp), "+v"(gq), "+v"(gr), "+v"(gs) : "v"(ga), "v"(gb));) }
+        if (V == 24) { REP16(asm volatile("v_mul_f64 %0, %0, %4\n\tv_mul_f64 %1, %1, %4\n\tv_mul_f64 %2, %2, %4\n\tv_mul_f64 %3, %3, %4"
+                                           : "+v"(fp), "+v"(fq), "+v"(fr), "+v"(fs) : "v"(fa));) }
         if (V == 0) { REP16(asm volatile("v_mad_u64_u32 %0, %4, %5, %6, %0\n\tv_mad_u64_u32 %1, %4, %6, %7, %1\n\tv_mad_u64_u32 %2, %4, %7, %8, %2\n\tv_mad_u64_u32 %3, %4, %8, %5, %3"
                                           : "+v"(p), "+v"(q), "+v"(r), "+v"(s), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }                  // 4 independent accumulators
         if (V == 1) { REP16(asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %5, %2, %0"
@@ -62,7 +73,7 @@ template <int V> __global__ void __launch_bounds__(256) kb(uint32_t *out, uint32
         if (V == 14) { REP16(asm volatile("v_mad_i64_i32 %0, %4, %5, %6, %0\n\tv_mad_i64_i32 %1, %4, %6, %7, %1\n\tv_mad_i64_i32 %2, %4, %7, %8, %2\n\tv_mad_i64_i32 %3, %4, %8, %5, %3"
                                            : "+v"(p), "+v"(q), "+v"(r), "+v"(s), "=&s"(cc) : "v"(a), "v"(b), "v"(c), "v"(d));) }
     }
-    out[t] = c2 + e0 + e1 + a + b + c + d + (uint32_t)p + (uint32_t)q + (uint32_t)r + (uint32_t)s + (uint32_t)((p ^ q ^ r ^ s) >> 32);
+    out[t] = (uint32_t)(fp + fq + fr + fs) + (uint32_t)(gp + gq + gr + gs) + c2 + e0 + e1 + a + b + c + d + (uint32_t)p + (uint32_t)q + (uint32_t)r + (uint32_t)s + (uint32_t)((p ^ q ^ r ^ s) >> 32);
 #endif
 }
 
@@ -82,6 +93,10 @@ template <int V> static void run(uint32_t *d_out, const char *name) {
 
 int main() {
     uint32_t *d_out; (void)hipMalloc(&d_out, (size_t)256 * 8 * 256 * 4);
+    run<21>(d_out, "v_fma_f64 x4 independent");
+    run<22>(d_out, "v_add_f64 x4 independent");
+    run<24>(d_out, "v_mul_f64 x4 independent");
+    run<23>(d_out, "v_fma_f32 x4 independent");
     run<0>(d_out, "v_mad_u64_u32 x4 independent");
     run<1>(d_out, "v_mad_u64_u32 one accumulator");
     run<10>(d_out, "v_mad_u64_u32 + v_addc (column pattern)");
