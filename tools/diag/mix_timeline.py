@@ -93,16 +93,32 @@ for q, ks in by_stream.items():
         if ks[i][2].startswith("k_bucket_chunks") and t0 <= ks[i][0] < tend:
             a, b = ks[i - 1][1], ks[i][0]
             if b > a:
-                c = covered(a, b)
-                gaps.append((b - a, c, ks[i - 1][2]))
+                gaps.append((b - a, covered(a, b), ks[i - 1][2]))
+            else:
+                gaps.append((0, 0, ks[i - 1][2]))              # back to back (the profiler's end stamp of one dispatch may even lie after the next one's start)
 if gaps:
-    tot = sum(g[0] for g in gaps); cov = sum(g[1] for g in gaps)
-    print("sweeps in the window: %d; gap between the end of the stream's previous kernel and the sweep's start: mean %.1f us, total %.1f ms per proof" % (len(gaps), tot / len(gaps) / 1e3, tot / 1e6 / max(proofs, 1)))
-    print("    of that gap, another stream's wide kernel was running %.1f %% of the time (device busy), none %.1f %% (dependency, host, launch)" % (100 * cov / tot, 100 * (tot - cov) / tot))
+    tot = sum(g[0] for g in gaps); cov = sum(g[1] for g in gaps); waited = [g for g in gaps if g[0] > 0]
+    print("sweeps in the window: %d; %d of them (%.1f %%) start back to back with the previous kernel of their stream; the others wait %.1f us on average; all gaps together: %.3f ms per proof"
+          % (len(gaps), len(gaps) - len(waited), 100.0 * (len(gaps) - len(waited)) / len(gaps), (tot / len(waited) / 1e3) if waited else 0.0, tot / 1e6 / max(proofs, 1)))
+    if tot:
+        print("    of the waiting time, another stream's wide kernel was running %.1f %% (device busy), none %.1f %% (dependency, host, launch)" % (100 * cov / tot, 100 * (tot - cov) / tot))
     prev = collections.Counter()
     for g in gaps:
         prev[g[2]] += 1
     print("    kernel that precedes a sweep on its stream: " + ", ".join("%s x%d" % kv for kv in prev.most_common(4)))
+# per stream: share of the window with no kernel of that stream resident (host-side work between rounds: encode L/R, transcript, challenge, recoding)
+idle = []
+for q, ks in by_stream.items():
+    ks = sorted((max(s, t0), min(e, tend)) for s, e, n in ks if e > t0 and s < tend)
+    if len(ks) < 100:
+        continue
+    busy, cur = 0, t0
+    for s_, e_ in ks:
+        if e_ > cur:
+            busy += e_ - max(s_, cur); cur = e_
+    idle.append(100.0 * (span - busy) / span)
+if idle:
+    print("proving streams: %d; share of the window a stream has no kernel resident (its host thread works between rounds): %s %%" % (len(idle), ", ".join("%.1f" % x for x in sorted(idle))))
 # how long do kernels of each group take in the mix (duration = residency, not work)
 dur = collections.defaultdict(list)
 for s, e, n, q in sel:

@@ -8,9 +8,15 @@
 #   pmc    two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only                -> gpurun_out/<tag>_pmc_fetch/, <tag>_pmc_write/, <tag>_pmc_traffic.json
 #   pmcthr the same two --pmc passes over `bench.py --in-flight-only` (the concurrent mix of the throughput leg)               -> gpurun_out/<tag>_pmc_traffic_throughput.json
 #   bench  the default bench line exactly as the driver runs it (cpu_baseline, throughput, batch) -> gpurun_out/<tag>_bench_plain.json
+#   insts  VALU instruction budget of a proof per kernel under the shared-device variants (tools/diag/insts.sh: one --pmc pass, SQ counters) -> <tag>_insts_summary.{txt,json}
+#   mix    rocprofv3 kernel trace of `bench.py --in-flight-only` -> gap analysis (tools/diag/mix_timeline.py) -> <tag>_mix_timeline.txt
+#   mask   the concurrent mix with every gathered point index masked to an L2-resident table against the product build, alternating
+#          (tools/diag/mask_build.sh must have built tools/diag/libbpg_hip_mask.so in the build container) -> <tag>_mask_ab.txt
+#   clock  shader clock and board power while the mix / one stream runs (tools/diag/clock_watch.py) -> <tag>_clock.txt
+#   appetite  value / HBM / busy cores for {serving, one-shot} x {20, 10, 6} streams (tools/diag/appetite.sh) -> <tag>_appetite.txt
 # rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
 set -o pipefail
-tag=${1:-r03}; shift
+tag=${1:-r04}; shift
 stages=${*:-calib stats pmc bench}
 root=$(pwd)
 out=$root/gpurun_out
@@ -59,5 +65,29 @@ fi
 if has bench; then
     timeout -k 10 800 python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_plain.json" 2> "$out/${tag}_bench_plain.err" || { echo "bench failed"; tail -5 "$out/${tag}_bench_plain.err"; exit 1; }
     echo "bench done"
+fi
+if has insts; then
+    bash "$root/tools/diag/insts.sh" "$tag" BPG_PROFILE=serving BPG_FOLD_ADAPT=2 > "$out/${tag}_insts.log" 2>&1 || { echo "insts failed"; tail -5 "$out/${tag}_insts.log"; exit 1; }
+    echo "insts done"
+fi
+if has mix; then
+    (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d "$out/${tag}_mixtrace" -o "$tag" -- python3 "$root/bench.py" --in-flight-only --in-flight-steps 32 > "$out/${tag}_mixtrace.json" 2> "$out/${tag}_mixtrace.err") || { echo "mix trace failed"; tail -5 "$out/${tag}_mixtrace.err"; exit 1; }
+    python3 "$root/tools/diag/mix_timeline.py" "$(csv "$out/${tag}_mixtrace" kernel_trace.csv)" 2.0 > "$out/${tag}_mix_timeline.txt" || exit 1
+    rm -rf "$out/${tag}_mixtrace"
+    echo "mix done"
+fi
+if has mask; then
+    [ -f "$root/tools/diag/libbpg_hip_mask.so" ] || { echo "tools/diag/libbpg_hip_mask.so missing: run tools/diag/mask_build.sh in the build container"; exit 1; }
+    bash "$root/tools/diag/ab.sh" "$root/bulletproofs_gadgets_amd/libbpg_hip.so" "$root/tools/diag/libbpg_hip_mask.so" 3 --in-flight-steps 48 > "$out/${tag}_mask_ab.txt" 2>&1 || { echo "mask A/B failed"; tail -5 "$out/${tag}_mask_ab.txt"; exit 1; }
+    echo "mask done"
+fi
+if has clock; then
+    python3 "$root/tools/diag/clock_watch.py" "mix (6 proving streams)" -- python3 "$root/bench.py" --in-flight-only --in-flight-steps 48 > "$out/${tag}_clock.txt" 2> "$out/${tag}_clock.err" || true
+    python3 "$root/tools/diag/clock_watch.py" "one stream" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 5 --warmup 2 >> "$out/${tag}_clock.txt" 2>> "$out/${tag}_clock.err" || true
+    echo "clock done"
+fi
+if has appetite; then
+    bash "$root/tools/diag/appetite.sh" > "$out/${tag}_appetite.txt" 2>&1 || true
+    echo "appetite done"
 fi
 find "$out" -name "*kernel_stats.csv" -o -name "*counter_collection.csv" | head
