@@ -243,7 +243,7 @@ struct Engine::Impl {
     DevBuf gens;                                // view of shared->gens (not owned)
     DevBuf bases, scratch_ext, comp, small_in, small_sc;
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, open_keys, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
+    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, open_keys, medium, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
     uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 4 per CU of the device the context is created on (BPG_SWEEP_RESIDENT overrides)
     uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps)
     uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (digits are 16-bit)
@@ -318,7 +318,7 @@ struct Engine::Impl {
     // cut into `fold_parts` pieces of L bits); built on first use for the device's generator tables and shared with them
     DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
     uint32_t fold_wnaf = 6;          // width of the NAF the first fold recodes its scalars in (BPG_FOLD_WNAF; one-shot profile 6, serving 8; 0 = register kernels)
-    uint32_t fold_parts = 1;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2 or 4; serving 4)
+    uint32_t fold_parts = 1;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2, 4 or 8; serving 4)
     uint64_t fold_table_budget = 64ull << 30;       // per-kind cap of the fold tables (BPG_FOLD_TABLE_GB); the cumulative bound is table_budget
     uint32_t eff_wnaf = 0, eff_parts = 0;            // what odd_ensure settled on for the current capacity
     uint32_t fold_part_bits() const { return (254 + eff_parts - 1) / eff_parts; }
@@ -530,7 +530,7 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     env_set("BPG_FOLD_GROUP", 1, 5, K->fold_group);
     if (env_present("BPG_TT_WIDE_GB")) K->tt_wide_budget = (uint64_t)(env_double_strict("BPG_TT_WIDE_GB", 0.0, 4096.0) * (double)(1ull << 30));
     if (env_present("BPG_FOLD_TABLE_GB")) K->fold_table_budget = (uint64_t)(env_double_strict("BPG_FOLD_TABLE_GB", 0.0, 4096.0) * (double)(1ull << 30));
-    if (env_present("BPG_FOLD_PARTS")) { const long v = env_int_strict("BPG_FOLD_PARTS", 1, 4); if (v == 3) throw std::invalid_argument("BPG_FOLD_PARTS: 1, 2 or 4"); K->fold_parts = (uint32_t)v; }
+    if (env_present("BPG_FOLD_PARTS")) { const long v = env_int_strict("BPG_FOLD_PARTS", 1, 8); if (v & (v - 1)) throw std::invalid_argument("BPG_FOLD_PARTS: 1, 2, 4 or 8"); K->fold_parts = (uint32_t)v; }
     if (env_present("BPG_FOLD_WNAF")) { const long v = env_int_strict("BPG_FOLD_WNAF", 0, 8); if (v == 1 || v == 2) throw std::invalid_argument("BPG_FOLD_WNAF: 0 (register kernels) or 3..8"); K->fold_wnaf = (uint32_t)v; }
     if (env_present("BPG_TT_LG")) K->tt_lg = K->tt_orig_lg = (uint32_t)env_int_strict("BPG_TT_LG", 0, 20);
     env_set("BPG_TT_ORIG_LG", 0, 20, K->tt_orig_lg);
@@ -582,7 +582,7 @@ Engine::~Engine() {
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
@@ -883,7 +883,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         CH = (uint32_t)std::max<uint64_t>(4, (Mub + slots * rounds - 1) / (slots * rounds));
     }
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, CH);
-    heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4);
+    heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4); medium.ensure(((size_t)nchunks / 2 + 2) * 4);      // a bucket on the medium list crosses at least two boundaries
     {
         // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
         const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
@@ -893,7 +893,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         entries1.ensure((size_t)(total ? total : 1) * W * 4);
         counts.ensure((size_t)(nflat + 1) * 4); starts1.ensure((size_t)(nflat + 1) * 4); cursor.ensure((size_t)(nflat + 1) * 4);
         blocksum.ensure((size_t)(nblk1 + 1) * 4);
-        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits.as<uint16_t>(), heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits.as<uint16_t>(), heavy.as<uint32_t>(), medium.as<uint32_t>());
         HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
         if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits.as<uint16_t>(), total, counts.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
@@ -916,10 +916,10 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         // joining the pieces of buckets that cross chunk boundaries: one thread per boundary where chunks are at least as long as the average bucket
         // (the shared-device shape: 64-entry chunks, ~32 entries per bucket), one thread per bucket where buckets are longer (a proof alone)
         if ((uint64_t)CH * nkeys >= Mub)
-            BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nchunks, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, open_keys.as<uint32_t>(), nkeys, CH, heavy.as<uint32_t>());
+            BPG_LAUNCH((*this), k_bucket_combine, dim3(cdiv(nchunks, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, open_keys.as<uint32_t>(), nkeys, CH, heavy.as<uint32_t>(), medium.as<uint32_t>());
         else
             BPG_LAUNCH_ID((*this), KID_k_bucket_combine, k_bucket_combine_per_bucket, dim3(cdiv(nkeys, 256)), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, nkeys, CH, heavy.as<uint32_t>());
-        BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, CH, heavy.as<uint32_t>());
+        BPG_LAUNCH((*this), k_bucket_combine_heavy, dim3(512), dim3(256), starts.as<uint32_t>(), buckets.as<ge_ext>(), slotA, slotB, CH, heavy.as<uint32_t>(), medium.as<uint32_t>());
     }
     const uint32_t nred = nmsm * W * nsegpw;
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), starts.as<uint32_t>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);

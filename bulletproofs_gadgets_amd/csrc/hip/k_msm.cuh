@@ -73,9 +73,10 @@ __device__ __forceinline__ uint32_t msm_lds_take(uint32_t *ctr, uint32_t key, bo
     }
     return active ? atomicAdd(&ctr[key], 1u) : 0u;
 }
-__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ heavy_count) {
+__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ heavy_count,
+                                                    uint32_t *__restrict__ medium_count) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) *heavy_count = 0;                            // list of k_bucket_combine, filled later on this stream
+    if (g == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
     if (g >= total) return;
     const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
     uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
@@ -347,7 +348,8 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
 __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                         const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
                                                         const uint32_t *__restrict__ open_key, uint32_t nkeys, uint32_t CH,
-                                                        uint32_t *__restrict__ heavy /* [0] = count, then keys */) {
+                                                        uint32_t *__restrict__ heavy /* [0] = count, then keys */,
+                                                        uint32_t *__restrict__ medium /* [0] = count, then keys: buckets with pieces beyond the second */) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M = starts[nkeys];
     if ((uint64_t)c * CH >= M) return;                           // the sweep had no such chunk (open_key[c] was not written)
@@ -355,9 +357,18 @@ __global__ void __launch_bounds__(256) k_bucket_combine(const uint32_t *__restri
     if (k == MSM_NO_KEY) return;
     const uint32_t c1 = (starts[k + 1] - 1) / CH;
     if (c1 - c > HEAVY_CHUNKS) { heavy[1 + atomicAdd(&heavy[0], 1u)] = k; return; }
-    ge_ext acc = slotB[c];
-    for (uint32_t cc = c + 1; cc <= c1; cc++) acc = ge_add(acc, slotA[cc]);
-    buckets[k] = acc;
+    // exactly ONE addition per lane here: a bucket that crosses a second boundary (a few per cent of them) would make its whole wave run the
+    // addition again, so its remaining pieces go on a compacted list that k_bucket_combine_heavy finishes with one thread per bucket
+    buckets[k] = ge_add(slotB[c], slotA[c + 1]);
+    const bool more = c1 > c + 1;
+    const uint64_t vote = __ballot(more);
+    if (vote) {                                                  // one counter update per wave
+        const uint32_t lane = threadIdx.x & 63u, lead = (uint32_t)__ffsll((unsigned long long)vote) - 1u;
+        uint32_t base = 0;
+        if (lane == lead) base = atomicAdd(&medium[0], (uint32_t)__popcll(vote));
+        base = __shfl(base, lead, 64);
+        if (more) medium[1 + base + (uint32_t)__popcll(vote & ((1ull << lane) - 1ull))] = k;
+    }
 }
 // The same join with one thread per BUCKET: the better shape when buckets are longer than chunks (a proof alone on the device: 15-bit windows, 64
 // entries per bucket, 34-entry chunks - every bucket crosses two or three boundaries, so every lane has its two additions, while two of three
@@ -376,10 +387,10 @@ __global__ void __launch_bounds__(256) k_bucket_combine_per_bucket(const uint32_
     for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
     buckets[k] = acc;
 }
-// one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS
+// one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS; then the medium list, one thread per bucket
 __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                               const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
-                                                              uint32_t CH, const uint32_t *__restrict__ heavy) {
+                                                              uint32_t CH, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ medium) {
     __shared__ ge_ext lds[256];
     const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     ge_ext *L = lds + wv * 64;
@@ -396,6 +407,15 @@ __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__
         }
         if (lane == 0) buckets[k] = L[0];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // the medium list of k_bucket_combine: buckets[k] already holds the first two pieces; one thread adds the remaining ones
+    const uint32_t mcount = medium[0];
+    for (uint32_t it = blockIdx.x * blockDim.x + threadIdx.x; it < mcount; it += gridDim.x * blockDim.x) {
+        const uint32_t k = medium[1 + it];
+        const uint32_t c0 = starts[k] / CH, c1 = (starts[k + 1] - 1) / CH;
+        ge_ext acc = buckets[k];
+        for (uint32_t c = c0 + 2; c <= c1; c++) acc = ge_add(acc, slotA[c]);
+        buckets[k] = acc;
     }
 }
 

@@ -196,9 +196,11 @@ def test_msm_epilogue_and_sweep_knobs_give_the_oracle_sum(env, monkeypatch):
                 s = [rs(b"ks", i) for i in range(count)]
                 t = [rs(b"kt", i) for i in range(count)]
                 for i in range(0, count, 3):
-                    t[i] = sc(R.L - 2)                          # a third of the terms in ONE bucket of every window
+                    t[i] = sc(R.L - 2)                          # a third of the terms in ONE bucket of every window (the heavy list)
                 for i in range(1, count, 11):
                     s[i] = bytes(32)
+                for i in range(2, count, 75):
+                    s[i] = sc(0x123456789abcdef0fedcba9876543211)   # up to 40 equal scalars: a bucket over a handful of chunks (the medium list of k_bucket_combine)
                 assert c.msm_gens(3, s, t) == O.msm(b"".join(s + t), G + Hh, 1), (env, cmin, count)
         finally:
             c.close()
