@@ -464,7 +464,18 @@ def spawn_batch_ranks(mode, batch_file, gpus):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % gpus, "--master-addr", "127.0.0.1", "--master-port", str(port),
            "-m", "bulletproofs_gadgets_amd.cli", mode, "--batch", batch_file, "--gpus", str(gpus)]
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' own verdict (0, 1 = a proof rejected, 101 = a stem failed) travels through a file: the elastic launcher turns every non-zero exit of a
+    # rank into 1 and a page of its own diagnostics, so the ranks of a batch that RAN exit 0 and rank 0 leaves the batch's exit code here
+    import tempfile
+    fd, rc_file = tempfile.mkstemp(prefix="bpg_batch_rc_")
+    os.close(fd)
+    env["BPG_BATCH_RC_FILE"] = rc_file
+    try:
+        launcher = subprocess.run(cmd, env=env).returncode
+        text = open(rc_file).read().strip()
+        return int(text) if launcher == 0 and text else (launcher or 101)
+    finally:
+        os.unlink(rc_file)
 
 
 def run_batch(mode, batch_file, gpus=1, seed=None, rng_seed=None, out=sys.stdout):
@@ -494,12 +505,20 @@ def run_batch(mode, batch_file, gpus=1, seed=None, rng_seed=None, out=sys.stdout
     ctx = Context(device)
     mine = shard_indices(len(stems), rank, world)
     local = {}
+    FAILED = (1 << 64) - 1                                                # constraint count of a stem that could not be proved
     for i in mine:
-        if mode == "prover":
-            p, proof = prover(stems[i], ctx, seed=seed, rng_seed=rng_seed, quiet=True)
-            local[i] = (p.num_constraints(), proof)
-        else:
-            local[i] = verifier(stems[i], ctx, quiet=True)
+        # ONE stem per try (as in csrc/cli_main.cpp): a missing or garbled file ends that stem only - it would end only its own run in the reference's
+        # CI (one prover process per stem, .github/workflows/integration_tests.yml:19-58) - and, with several ranks, must never keep this rank
+        # away from the collective the others are waiting in
+        try:
+            if mode == "prover":
+                p, proof = prover(stems[i], ctx, seed=seed, rng_seed=rng_seed, quiet=True)
+                local[i] = (p.num_constraints(), proof)
+            else:
+                local[i] = 1 if verifier(stems[i], ctx, quiet=True) else 0
+        except Exception as e:      # noqa: BLE001 - reported per stem below
+            sys.stderr.write("%s --batch (rank %d): %s: %s\n" % (mode, rank, stems[i], e))
+            local[i] = (FAILED, b"") if mode == "prover" else 2
     if mode == "prover":
         # the finished proofs cross the fabric as fixed-size records: constraints (8 B) | length (4 B) | proof bytes, padded to the longest proof of the batch
         longest = max([len(pr) for _, pr in local.values()] or [0])
@@ -515,16 +534,20 @@ def run_batch(mode, batch_file, gpus=1, seed=None, rng_seed=None, out=sys.stdout
         for stem, r in zip(stems, allrecs):
             n = int.from_bytes(r[8:12], "little")
             results.append((stem, int.from_bytes(r[:8], "little"), r[12:12 + n]))
+        results = [(stem, None, None) if q == FAILED else (stem, q, pr) for stem, q, pr in results]
         if rank == 0:
             for stem, q, pr in results:
-                out.write("%s: %d constraints, %d-byte proof, sha256 %s\n" % (stem, q, len(pr), hashlib.sha256(pr).hexdigest()[:16]))
+                if q is None:
+                    out.write("%s: FAILED\n" % stem)
+                else:
+                    out.write("%s: %d constraints, %d-byte proof, sha256 %s\n" % (stem, q, len(pr), hashlib.sha256(pr).hexdigest()[:16]))
     else:
-        recs = {i: bytes([1 if ok else 0]) for i, ok in local.items()}
+        recs = {i: bytes([v]) for i, v in local.items()}
         allrecs = gather_proofs(recs, len(stems), 1, dist, device=coll_device)
-        results = [(stem, r == b"\x01") for stem, r in zip(stems, allrecs)]
+        results = [(stem, None if r == b"\x02" else r == b"\x01") for stem, r in zip(stems, allrecs)]
         if rank == 0:
             for stem, ok in results:
-                out.write("%s: %s\n" % (stem, "true" if ok else "false"))
+                out.write("%s: %s\n" % (stem, "FAILED" if ok is None else ("true" if ok else "false")))
     out.flush()
     if dist is not None:
         dist.barrier()
@@ -549,7 +572,17 @@ def main(argv=None):
         seed = os.environ["BPG_CLI_SEED"].encode() if "BPG_CLI_SEED" in os.environ else None
         rng_seed = bytes.fromhex(os.environ["BPG_CLI_RNG_SEED"]).ljust(32, b"\0")[:32] if "BPG_CLI_RNG_SEED" in os.environ else None
         res = run_batch(argv[0], argv[2], gpus, seed=seed, rng_seed=rng_seed)
-        return 0 if argv[0] == "prover" or all(ok for _, ok in res) else 1
+        if any(r[1] is None for r in res):
+            rc = 101                                                      # a stem could not be processed: the exit code of the reference's panic
+        else:
+            rc = 0 if argv[0] == "prover" or all(ok for _, ok in res) else 1
+        rc_file = os.environ.get("BPG_BATCH_RC_FILE")                     # a rank started by spawn_batch_ranks: see there
+        if rc_file:
+            if int(os.environ.get("RANK", "0")) == 0:
+                with open(rc_file, "w") as f:
+                    f.write(str(rc))
+            return 0
+        return rc
     if len(argv) != 2 or argv[0] not in ("prover", "verifier"):
         print(__doc__)
         return 2

@@ -209,3 +209,18 @@ def test_a_broken_stem_fails_alone(tmp_path):
             for e in (".coms", ".proof"):
                 assert (d / (s + e)).read_bytes() == want[s + e], s + e
         assert "equality" in r.stderr or "or3" in r.stderr          # the first error text on stderr names its stem
+    # the Python driver: same behaviour, and with two ranks the rank that owns a broken stem still joins the gather the other one waits in
+    penv = dict(env, PYTHONPATH=str(ROOT) + os.pathsep + env.get("PYTHONPATH", ""), BPG_BATCH_BACKEND="gloo")
+    for extra in ([], ["--gpus", "2"]):
+        d = _stage(tmp_path / ("pybroken" + "_".join(extra)))
+        (d / "equality.wtns").unlink()
+        (d / "or3.gadgets").unlink()
+        (d / "or3.gadgets").write_text("BOUND W0 I0 I1\nFROBNICATE W0\n")
+        r = subprocess.run([sys.executable, "-m", "bulletproofs_gadgets_amd.cli", "prover", "--batch", "batch.txt"] + extra, cwd=d, env=penv,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 101, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = dict(l.split(": ", 1) for l in r.stdout.strip().splitlines() if ": " in l and l.split(": ")[0] in STEMS)
+        assert list(lines) == STEMS and lines["equality"] == "FAILED" and lines["or3"] == "FAILED"
+        for s in STEMS:
+            if s not in ("equality", "or3"):
+                assert "constraints" in lines[s] and (d / (s + ".proof")).read_bytes() == want[s + ".proof"], s
