@@ -547,6 +547,11 @@ class Prover:
         _chk(lib().bpg_prover_commit_precomputed(self._h, _exact("v", v, 32), _exact("v_blinding", v_blinding, 32), _exact("commitment", commitment, 32), C.byref(var)))
         return Variable(var.value)
 
+    def test_stub_commitments(self):
+        """bpg_test_prover_stub_commitments (TEST HOOK): commitments of this prover become 32 hash bytes of (value, blinding) made on the host - not group
+        elements - so that a device-less prover can run a driver's parsing and assembly under sanitizers; prove() stays refused."""
+        _chk(lib().bpg_test_prover_stub_commitments(self._h))
+
     def defer_commitments(self, on: bool = True):
         """Extension (bpg_prover_defer_commitments): while on, commit / commit_many / Gadget.setup register their variables and return zero bytes;
         flush_commitments() computes every pending commitment in one kernel launch and appends them to the transcript in commit order."""

@@ -425,3 +425,32 @@ def test_bad_environment_knobs_are_refused_at_context_creation(var, val, monkeyp
         bpg.Context(0)
     assert e.value.status == 4, (var, val, e.value.status, str(e.value))
     assert var in str(e.value)
+
+
+def test_stub_commitment_hook_is_device_less_and_never_proves():
+    """bpg_test_prover_stub_commitments (the hook behind tests/hostcheck/fuzz_cli): a prover WITHOUT a device context refuses to commit; with the hook
+    its commitments are 32 deterministic hash bytes (same value and blinding -> same bytes, in the per-call and in the deferred form), the variables
+    and the transcript move as usual, a gadget's setup works - and prove() still fails with BPG_ERR_DEVICE: the hook can never produce a proof."""
+    def build(deferred):
+        t = bpg.Transcript(b"stub")
+        p = bpg.Prover(None, t)
+        with pytest.raises(bpg.BpgError) as e:
+            p.commit(bpg.be_to_scalar(b"\x05"), bytes(32))
+        assert e.value.status == 7
+        p.test_stub_commitments()
+        if deferred:
+            p.defer_commitments(True)
+        c1, v1 = p.commit(bpg.be_to_scalar(b"\x05"), bytes([1]) + bytes(31))
+        c2, v2 = p.commit(bpg.be_to_scalar(b"\x06"), bytes([1]) + bytes(31))
+        bpg.range_proof(p, v1, 8, bpg.be_to_scalar(b"\x05"))
+        if deferred:
+            p.flush_commitments()
+            c1, c2 = p.commitment(0), p.commitment(1)
+        return p, t.state, c1, c2
+    p, st, c1, c2 = build(False)
+    pd, std, d1, d2 = build(True)
+    assert (c1, c2) == (d1, d2) and c1 != c2 and len(c1) == 32 and st == std
+    assert p.get_num_multiplications() == 8 and p.num_committed() == 2
+    with pytest.raises(bpg.BpgError) as e:
+        p.prove(8, bytes(32))
+    assert e.value.status == 7
