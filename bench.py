@@ -201,7 +201,7 @@ def source_hash():
     """Hash of the product sources the kernels are built from: a stored PMC profile is only quoted when it was taken from these sources."""
     h = hashlib.sha256()
     for p in sorted((ROOT / "bulletproofs_gadgets_amd" / "csrc").rglob("*")):
-        if p.is_file() and p.suffix in (".hip", ".cuh", ".hpp", ".inc", ".cpp"):
+        if p.is_file() and p.suffix in (".hip", ".cuh", ".hpp", ".inc"):          # what libbpg_hip.so is built from (cli_main.cpp is the file driver over the C ABI)
             h.update(p.name.encode()); h.update(p.read_bytes())
     return h.hexdigest()[:16]
 

@@ -721,6 +721,7 @@ static void crash_report(int sig) {
     signal(sig, SIG_DFL); raise(sig);
 }
 int main(int argc, char **argv) {
+    { void *warm[2]; (void)backtrace(warm, 2); }                              // loads the unwinder now: the handler must not allocate
     for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) signal(sig, crash_report);
     std::string self = argv[0]; size_t slash = self.rfind('/'); if (slash != std::string::npos) self = self.substr(slash + 1);
     std::string mode, name;
