@@ -304,6 +304,34 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
             "rate": "proofs completed after the first %d completions / time from that completion to the last" % skip}
 
 
+def file_config(ctx, workloads, which):
+    """A configuration that exists as FILES, assembled by the file driver (cli.prover(assemble_only): parsing, commitments and gadget assembly as
+    `prover NAME` does them, reference src/bin/prover.rs:47-91) and handed over just before Prover::prove:
+      example  BASELINE.json config 1: the reference's own example.gadgets / .inst / .wtns (reference example.gadgets:1-9; the repo keeps its three
+               input files as test data under tests/golden/resources/): n = 14,988, q = 30,007, m = 33
+      path20   SURVEY.md section 8(d) cfg 4b: one depth-20 Merkle authentication path (workloads.merkle_path_files): n = 39,852, N = 2^16"""
+    import shutil
+    import tempfile
+    from bulletproofs_gadgets_amd import cli
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)                                                       # the transcript label is the NAME argument (prover.rs:49-52): a fixed relative name
+        try:
+            if which == "example":
+                for ext in ("gadgets", "inst", "wtns"):
+                    shutil.copy(ROOT / "tests" / "golden" / "resources" / ("example." + ext), "example." + ext)
+            else:
+                workloads.merkle_path_files("path20", depth=20)
+            p, t = cli.prover(which, ctx=ctx, seed=b"bench", rng_seed=bytes(32), quiet=True, two_pass=False, assemble_only=True)
+        finally:
+            os.chdir(cwd)
+    n = p.get_num_multiplications()
+    cap = 1
+    while cap < n:
+        cap *= 2
+    return workloads.Assembled(p, t, [p.commitment(i) for i in range(p.num_committed())], cap, None)
+
+
 def small_configs(bpg, workloads, device):
     """Secondary: BASELINE.json's small configurations (parity cases, never `value`) - median prove / verify time of a lone proof under the library's
     default one-shot profile and under the serving profile of this benchmark (8-bit window tables for circuits up to 2^14 multipliers)."""
@@ -313,8 +341,10 @@ def small_configs(bpg, workloads, device):
         rows = {}
         try:
             for name, mk in (("cfg2_bounds_check_64", lambda: workloads.bounds_check_64(c, seed=0)),
+                             ("cfg1_example_gadgets", lambda: file_config(c, workloads, "example")),
                              ("cfg1_size_merkle8_2^14", lambda: workloads.merkle_full_tree(c, leaves=8, seed=7)),
-                             ("cfg3_mimc_preimage_2^16", lambda: workloads.mimc_preimage(c, nbytes=2130, seed=0, label=b"MiMCHash"))):
+                             ("cfg3_mimc_preimage_2^16", lambda: workloads.mimc_preimage(c, nbytes=2130, seed=0, label=b"MiMCHash")),
+                             ("cfg4b_merkle_path_depth20", lambda: file_config(c, workloads, "path20"))):
                 a = mk(); inst = a.prover.instance(); state = a.transcript.state
                 c.gens_ensure(a.gens_capacity); res = c.upload(inst)
                 for i in range(4):
@@ -886,8 +916,10 @@ def run_rank(args):
            "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": t_step * 1e3, "gates_per_s": float(inst.n) * world * args.steps / elapsed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u32", "dtype_note": "8 x u32 limbs: 255-bit modular integer arithmetic (v_mad_u64_u32), no floating point", "data": "synthetic",
-           "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545), one proof per GPU per step"
-                                  % args.leaves, "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
+           "config": {"workload": "full %d-leaf MiMC Merkle tree (reference merkle_tree_gadget.rs:473-545); a step = one independent proof (own seed) per GPU; the %d "
+                                  "timed steps run CONCURRENTLY on %d proving streams per GPU and ms_per_step = timed region / %d - a rate, not the latency of a "
+                                  "proof (that is single_proof_latency_ms; the sustained rate of a long sequence is throughput.ms_per_proof)"
+                                  % (args.leaves, args.steps, n_streams, args.steps), "n": inst.n, "N": a.gens_capacity, "q": inst.q, "m": inst.m,
                       "inputs": "flattened R1CS instance + generator tables resident in HBM", "rng": "Merlin TranscriptRng (upstream-exact)",
                       "chain": (("the steps are dealt round-robin to %d proving streams per GPU (engine contexts: own HIP stream and proving thread, generator tables "
                                  "shared); the serial TranscriptRng chains (one per proof, 2n+8 dependent Keccak-f, upstream-exact) are drawn by ONE pool of %d chain "

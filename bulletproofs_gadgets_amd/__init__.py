@@ -41,7 +41,7 @@ class R1CSInstance(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [(k, C.c_double) for k in ("rng_host", "msm_aiao", "msm_s", "poly", "ipa", "total", "ipa_msm", "ipa_fold", "ipa_sync", "shared_variants")]
+    _fields_ = [(k, C.c_double) for k in ("rng_host", "msm_aiao", "msm_s", "poly", "ipa", "total", "ipa_msm", "ipa_fold", "ipa_sync")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,7 +50,7 @@ class Timings(C.Structure):
 class Config(C.Structure):
     """bpg_config (include/bpg.h): zero / None fields fall back to the BPG_* environment variable, then to the profile's default."""
     _fields_ = [("struct_size", C.c_uint32), ("profile", C.c_uint32), ("table_budget_gb", C.c_double), ("chain_workers", C.c_uint32),
-                ("chain_lanes", C.c_uint32), ("blocking_sync", C.c_uint32), ("gens_cache_dir", C.c_char_p)]
+                ("chain_lanes", C.c_uint32), ("blocking_sync", C.c_int32), ("gens_cache_dir", C.c_char_p)]
 
 
 PROFILE_DEFAULT, PROFILE_ONESHOT, PROFILE_SERVING = 0, 1, 2
@@ -63,7 +63,7 @@ def make_config(profile=None, table_budget_gb=None, chain_workers=None, chain_la
     cfg.profile = _PROFILES[profile]
     cfg.table_budget_gb = float(table_budget_gb or 0)
     cfg.chain_workers, cfg.chain_lanes = int(chain_workers or 0), int(chain_lanes or 0)
-    cfg.blocking_sync = 0 if blocking_sync is None else (1 if blocking_sync else 2)      # 0 unset, 1 blocking, 2 spin
+    cfg.blocking_sync = -1 if blocking_sync is None else (1 if blocking_sync else 0)      # -1 unset (environment, else spin), 1 blocking, 0 spin
     cfg.gens_cache_dir = os.fsencode(gens_cache_dir) if gens_cache_dir else None
     return cfg
 

@@ -24,6 +24,7 @@ import sys
 from . import (BoundsCheck, BulletproofGens, ConstraintBuffer, Context, Equality, or_conjunction, Inequality, LessThan, MerkleTree256, MimcHash256, Prover,
                SetMembership, Transcript, Verifier, be_to_scalar, be_to_scalars, commit, commit_single, mimc_hash, scalar_to_be, L)
 
+MAX_OR_NESTING = 64      # OR blocks may nest (reference src/bin/prover.rs:219-234); the file is untrusted input, so the recursion is bounded (csrc/cli_main.cpp: same bound)
 _VAR = re.compile(r"^\s*([A-Za-z][0-9]+(?:-[0-9]+){0,2})\s*=\s*0[xX]([0-9a-fA-F]+)\s*$")
 
 
@@ -90,14 +91,25 @@ def parse_tree(text):
     return inst, wit, pat
 
 
-def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_pass=None):
+def _setup(g, p, scalars, blindings):
+    """Gadget::setup (reference src/gadget.rs:18-38); a prover that makes its commitments outside the library brings its own (workloads._setup)"""
+    return p.gadget_setup(g, scalars, blindings) if hasattr(p, "gadget_setup") else g.setup(p, scalars, blindings)
+
+
+def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_pass=None, prover_cls=None, assemble_only=False):
     """two_pass (default: on, BPG_CLI_TWO_PASS=0 turns it off): every commitment of the .gadgets file is made first (pass 1: Gadget::setup's
     derived witnesses and hash_witness's images depend on witness and instance bytes only), the TranscriptRng chain of prove() starts on the
     context's chain worker as soon as the transcript is final (Prover.start_blinding), and pass 2 assembles the constraints beside it, replaying
-    the cached commitments.  Same blinding draws, same .coms lines, same transcript, same proof bytes as the reference's single pass."""
-    ctx = ctx or Context(0)
+    the cached commitments.  Same blinding draws, same .coms lines, same transcript, same proof bytes as the reference's single pass.
+    assemble_only: stop before prove() and return (prover, transcript) - the statement as prove() would receive it (bench.py times the proof of a file
+    configuration alone; tests/golden/gen_big_proof_fixtures.py hands it to the oracle).  prover_cls: a Prover subclass (the fixture generator's, which
+    takes its commitments from the oracle and needs no device)."""
+    if prover_cls is None:
+        ctx = ctx or Context(0)
     if two_pass is None:
         two_pass = os.environ.get("BPG_CLI_TWO_PASS", "1") != "0"
+    if prover_cls is not None:
+        two_pass = False                                                  # no device context: no blinding stream to start early
     rng_seed = rng_seed if rng_seed is not None else os.urandom(32)
     st = {"pass": 0, "cache": [], "pos": 0, "est": 0, "or": False}
 
@@ -116,7 +128,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
             g.prove(cs, vars_, derived)
     rnd = _Blindings(seed)
     transcript = Transcript(name.encode())
-    p = Prover(ctx, transcript)
+    p = (prover_cls or Prover)(ctx, transcript)
     instance = dict(_read_vars(name + ".inst"))
     witness = {}
     coms_lines = []
@@ -149,7 +161,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
         image = mimc_hash(w[3])
         _, image_com, image_var = cached(lambda: commit_single(p, scalar_to_be(image), rnd.next()))
         hg = MimcHash256(image_var)
-        dcoms, derived = cached(lambda: hg.setup(p, w[0], rnd.take(2)))
+        dcoms, derived = cached(lambda: _setup(hg, p, w[0], rnd.take(2)))
         assemble(hg, cs, w[2], derived)
         st["est"] += 972 * (len(w[0]) + 1)
         derived_lines([image_com] + dcoms, index, sub)
@@ -167,14 +179,14 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
             lo, hi = instance[parts[2]], instance[parts[3]]
             g = BoundsCheck(lo, hi)
             st["est"] += 16 * len(hi)
-            dcoms, derived = cached(lambda: g.setup(p, w[0], rnd.take(2)))
+            dcoms, derived = cached(lambda: _setup(g, p, w[0], rnd.take(2)))
             assemble(g, cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "HASH":                                                # prover.rs:278-305
             g = MimcHash256(lc_of(parts[1]))
             w = witness[parts[2]]
             st["est"] += 972 * (len(w[0]) + 1)
-            dcoms, derived = cached(lambda: g.setup(p, w[0], rnd.take(2)))
+            dcoms, derived = cached(lambda: _setup(g, p, w[0], rnd.take(2)))
             assemble(g, cs, w[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "MERKLE":                                              # prover.rs:307-339
@@ -192,7 +204,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
             l, r = single(parts[1]), single(parts[2])
             g = LessThan(l[2][0], l[0][0], r[2][0], r[0][0])
             st["est"] += 379
-            dcoms, derived = cached(lambda: g.setup(p, [], rnd.take(2)))
+            dcoms, derived = cached(lambda: _setup(g, p, [], rnd.take(2)))
             assemble(g, cs, [], derived)
             derived_lines(dcoms, index, 0)
         elif op == "UNEQUAL":                                             # prover.rs:384-418
@@ -204,7 +216,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
                 rs_ = be_to_scalars(instance[right]); rl = rs_
             g = Inequality(rl, rs_)
             st["est"] += 2 * len(lw[0]) + 1
-            dcoms, derived = cached(lambda: g.setup(p, lw[0], rnd.take(2 * len(lw[0]) + 1)))
+            dcoms, derived = cached(lambda: _setup(g, p, lw[0], rnd.take(2 * len(lw[0]) + 1)))
             assemble(g, cs, lw[2], derived)
             derived_lines(dcoms, index, 0)
         elif op == "SET_MEMBER":                                          # prover.rs:420-532
@@ -244,14 +256,16 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
                         h = mimc_hash(instance[e]); i_lcs.append(h); i_scalars.append(h)
             g = SetMembership(m_lc, m_scalar, i_lcs, i_scalars)
             st["est"] += 2 * (len(w_scalars) + len(i_scalars))
-            dcoms, derived = cached(lambda: g.setup(p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars))))
+            dcoms, derived = cached(lambda: _setup(g, p, w_scalars, rnd.take(len(w_scalars) + len(i_scalars))))
             assemble(g, cs, w_vars, derived)
             derived_lines(dcoms, index, 0)
         else:
             raise ValueError("unknown gadget line: %r" % line)
 
-    def run_block(i, cs, closing):
+    def run_block(i, cs, closing, depth=0):
         """lines from i on; closing = None at top level, "]" inside an OR block (prover.rs:75-84 and :219-234)"""
+        if depth > MAX_OR_NESTING:
+            raise ValueError("OR blocks nested deeper than %d" % MAX_OR_NESTING)
         while i < len(lines):
             line, index = lines[i], i
             i += 1
@@ -264,7 +278,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
             if st["pass"] == 1:                                           # commitments only: OR clauses are walked in file order, nothing is recorded
                 if op == "OR":
                     st["or"] = True
-                    i = run_block(i, cs, "]")
+                    i = run_block(i, cs, "]", depth + 1)
                 elif op not in ("}", "[", "{"):
                     do_gadget(line, index, cs)
                 continue
@@ -272,7 +286,7 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
                 cs.rewind()                                               # end of a clause
             elif op == "OR":
                 child = ConstraintBuffer(cs, True)
-                i = run_block(i, child, "]")
+                i = run_block(i, child, "]", depth + 1)
                 or_conjunction(cs, child)
             elif op in ("[", "{"):
                 pass
@@ -293,6 +307,8 @@ def prover(name, ctx=None, seed=None, rng_seed=None, flags=0, quiet=False, two_p
         run_block(0, p, None)
     if not quiet:
         print(p.num_constraints())                                        # prover.rs:89
+    if assemble_only:
+        return p, transcript
     cap = round_pow2(p.get_num_multiplications())
     proof = p.prove(BulletproofGens(ctx, cap), rng_seed, flags)
     with open(name + ".coms", "w") as f:
@@ -406,7 +422,9 @@ def assemble_verifier(name):
         else:
             raise ValueError("unknown gadget line: %r" % line)
 
-    def run_block(i, cs, closing):
+    def run_block(i, cs, closing, depth=0):
+        if depth > MAX_OR_NESTING:
+            raise ValueError("OR blocks nested deeper than %d" % MAX_OR_NESTING)
         while i < len(lines):
             line, index = lines[i], i
             i += 1
@@ -420,7 +438,7 @@ def assemble_verifier(name):
                 cs.rewind()
             elif op == "OR":                                              # verifier.rs:162-186
                 child = ConstraintBuffer(cs, False)
-                i = run_block(i, child, "]")
+                i = run_block(i, child, "]", depth + 1)
                 or_conjunction(cs, child)
             elif op in ("[", "{"):
                 pass

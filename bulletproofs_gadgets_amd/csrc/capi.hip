@@ -87,6 +87,7 @@ Variable Prover::commit_precomputed(const Scalar &v, const Scalar &v_blinding, c
 
 std::vector<uint8_t> Prover::prove(uint64_t gens_capacity, const uint8_t rng_seed[32], uint32_t flags) {
     if (!engine_) throw DeviceError("this prover has no device context: prove() needs the GPU engine");
+    if (stub_commitments_) throw DeviceError("this prover holds stub (hash) commitments: prove() is refused");      // (test hook; cannot be set on a prover with an engine)
     flush_commitments();
     engine_->gens_ensure(gens_capacity);
     uint64_t N = 1; while (N < aL_.size()) N <<= 1;
@@ -170,6 +171,7 @@ const char *bpg_strerror(bpg_status s) {
     }
 }
 const char *bpg_last_error(void) { return g_last_error.c_str(); }
+uint32_t bpg_abi_version(void) { return BPG_ABI_VERSION; }
 
 static EngineConfig engine_config(const bpg_config *c) {
     EngineConfig e;
@@ -194,7 +196,9 @@ bpg_status bpg_ctx_create_ex(int32_t device, const bpg_config *config, bpg_ctx *
 bpg_status bpg_ctx_create(int32_t device, bpg_ctx **out) { return bpg_ctx_create_ex(device, nullptr, out); }
 int32_t bpg_device_count(void) { return Engine::device_count(); }
 bpg_status bpg_test_fail_next_upload(bpg_ctx *ctx) { return guard([&] { REQUIRE(ctx); ctx->engine->test_fail_next_upload(); }); }
+bpg_status bpg_test_drop_next_upload(bpg_ctx *ctx) { return guard([&] { REQUIRE(ctx); ctx->engine->test_drop_next_upload(); }); }
 uint64_t bpg_table_bytes(bpg_ctx *ctx) { return ctx ? ctx->engine->table_bytes() : 0; }
+int32_t bpg_ctx_last_shared_variants(bpg_ctx *ctx) { return ctx && ctx->engine->last_shared_variants() ? 1 : 0; }
 void bpg_ctx_destroy(bpg_ctx *ctx) { if (ctx) { delete ctx->engine; delete ctx; } }
 bpg_status bpg_pedersen_bases(bpg_ctx *ctx, uint8_t B[32], uint8_t Bb[32]) { return guard([&] { REQUIRE(ctx && B && Bb); ctx->engine->pedersen_bases(B, Bb); }); }
 bpg_status bpg_gens_ensure(bpg_ctx *ctx, uint64_t capacity) { return guard([&] { REQUIRE(ctx); ctx->engine->gens_ensure(capacity); }); }
@@ -235,7 +239,7 @@ void bpg_r1cs_free(bpg_ctx *ctx, bpg_circuit *c) { if (ctx && c) { ctx->engine->
 static void copy_timings(const ProveTimings &t, bpg_timings *o) {
     if (!o) return;
     o->rng_host = t.rng_host; o->msm_aiao = t.msm_aiao; o->msm_s = t.msm_s; o->poly = t.poly; o->ipa = t.ipa; o->total = t.total;
-    o->ipa_msm = t.ipa_msm; o->ipa_fold = t.ipa_fold; o->ipa_sync = t.ipa_sync; o->shared_variants = (double)t.shared_variants;
+    o->ipa_msm = t.ipa_msm; o->ipa_fold = t.ipa_fold; o->ipa_sync = t.ipa_sync;
 }
 
 bpg_status bpg_r1cs_prove_resident(bpg_ctx *ctx, bpg_circuit *c, uint8_t ts[BPG_TRANSCRIPT_STATE_BYTES], uint64_t m, const uint8_t *v_blinding,

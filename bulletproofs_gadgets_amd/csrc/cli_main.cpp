@@ -39,6 +39,9 @@
 #include "../../include/bpg.h"
 
 namespace {
+// OR blocks may nest (reference src/bin/prover.rs:219-234 recurses on them too); a .gadgets file is untrusted input, so the recursion is bounded:
+// the reference's own stems nest one level deep
+constexpr unsigned MAX_OR_NESTING = 64;
 
 typedef std::vector<uint8_t> Bytes;
 
@@ -345,7 +348,8 @@ struct ProverRun {
     }
 
     // lines from i on; closing = 0 at top level, ']' inside an OR block (prover.rs:75-84 and :219-234)
-    size_t run_block(size_t i, const Cs &cs, char closing) {
+    size_t run_block(size_t i, const Cs &cs, char closing, unsigned depth = 0) {
+        if (depth > MAX_OR_NESTING) fail("OR blocks nested deeper than " + std::to_string(MAX_OR_NESTING));      // the file is untrusted input: bounded recursion
         while (i < lines.size()) {
             const std::string &line = lines[i]; size_t index = i++;
             std::vector<std::string> parts = split(line);
@@ -353,7 +357,7 @@ struct ProverRun {
             const std::string &op = parts[0];
             if (closing && op.size() == 1 && op[0] == closing) return i;
             if (pass == 1) {                                  // commitments only: clauses of OR blocks are walked in file order, nothing is recorded
-                if (op == "OR") { saw_or = true; i = run_block(i, cs, ']'); }
+                if (op == "OR") { saw_or = true; i = run_block(i, cs, ']', depth + 1); }
                 else if (op == "}" || op == "[" || op == "{") { }
                 else do_gadget(line, index, cs);
                 continue;
@@ -362,7 +366,7 @@ struct ProverRun {
             else if (op == "OR") {
                 BufferGuard child; chk(bpg_buffer_new(cs_next_multiplier(cs), 1, &child.b), "ProverBuffer::new");
                 Cs inner; inner.b = child.b;
-                i = run_block(i, inner, ']');
+                i = run_block(i, inner, ']', depth + 1);
                 if (cs.b) chk(bpg_or_buffer(cs.b, child.b), "or"); else chk(bpg_or_prover(cs.p, child.b), "or");
             } else if (op == "[" || op == "{") { /* block openers */ }
             else do_gadget(line, index, cs);
@@ -522,7 +526,8 @@ struct VerifierRun {
             g.verify(cs, w_vars, d);
         } else fail("unknown gadget line: '" + line + "'");
     }
-    size_t run_block(size_t i, const Cs &cs, char closing) {
+    size_t run_block(size_t i, const Cs &cs, char closing, unsigned depth = 0) {
+        if (depth > MAX_OR_NESTING) fail("OR blocks nested deeper than " + std::to_string(MAX_OR_NESTING));
         while (i < lines.size()) {
             const std::string &line = lines[i]; size_t index = i++;
             std::vector<std::string> parts = split(line);
@@ -533,7 +538,7 @@ struct VerifierRun {
             else if (op == "OR") {                                        // verifier.rs:162-186
                 BufferGuard child; chk(bpg_buffer_new(cs_next_multiplier(cs), 0, &child.b), "VerifierBuffer::new");
                 Cs inner; inner.b = child.b;
-                i = run_block(i, inner, ']');
+                i = run_block(i, inner, ']', depth + 1);
                 if (cs.b) chk(bpg_or_buffer(cs.b, child.b), "or"); else chk(bpg_or_verifier(cs.v, child.b), "or");
             } else if (op == "[" || op == "{") { }
             else do_gadget(line, index, cs);
@@ -718,11 +723,18 @@ static void crash_report(int sig) {
     (void)!write(2, msg, sizeof msg - 1);
     void *frames[48];
     backtrace_symbols_fd(frames, backtrace(frames, 48), 2);
-    signal(sig, SIG_DFL); raise(sig);
+    raise(sig);                                                               // SA_RESETHAND put the default action back: the process dies of the signal
 }
 int main(int argc, char **argv) {
     { void *warm[2]; (void)backtrace(warm, 2); }                              // loads the unwinder now: the handler must not allocate
-    for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) signal(sig, crash_report);
+    {   // on an alternate stack, so that a stack overflow reports too instead of dying silently inside its own handler
+        static char altstack[1 << 16];
+        stack_t ss; std::memset(&ss, 0, sizeof ss); ss.ss_sp = altstack; ss.ss_size = sizeof altstack;
+        (void)sigaltstack(&ss, nullptr);
+        struct sigaction sa; std::memset(&sa, 0, sizeof sa);
+        sa.sa_handler = crash_report; sa.sa_flags = SA_ONSTACK | SA_RESETHAND; sigemptyset(&sa.sa_mask);
+        for (int sig : {SIGSEGV, SIGBUS, SIGFPE, SIGILL, SIGABRT}) (void)sigaction(sig, &sa, nullptr);
+    }
     std::string self = argv[0]; size_t slash = self.rfind('/'); if (slash != std::string::npos) self = self.substr(slash + 1);
     std::string mode, name;
     {   // --batch FILE [--gpus N]   (and, for the ranks the command starts itself: --rank R --world N, results on descriptor 3)

@@ -199,11 +199,11 @@ struct DeviceCircuit {
 };
 
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
-#define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
-    X(k_sc_from_wide) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
+#define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
+    X(k_sc_from_wide) X(k_blind_poison) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_sum_points) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -255,6 +255,7 @@ struct Engine::Impl {
     uint32_t msm_cmin = 2;          // BPG_MSM_CMIN: narrowest window (tests: wide windows on small sums)
     // prove buffers
     DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
+    DevBuf stale_flag;              // one word, zero unless k_sc_from_wide met a poisoned (never uploaded) draw: checked before a proof leaves prove()
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
@@ -305,10 +306,15 @@ struct Engine::Impl {
             (void)hipGetLastError(); table.release(); bases8.release();
             table_bytes_add(shared->device, -(int64_t)bytes); shared->refused[key] = table_bytes_held(shared->device); return nullptr;
         }
-        BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
-        BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(st));
+        try {
+            BPG_LAUNCH((*this), k_tt_bases8, dim3(cdiv(2 * M0, 64)), dim3(256), gens.as<ge_niels>(), gens.as<ge_niels>() + gens_cap, bases8.as<ge_ext>(), M0);
+            BPG_LAUNCH((*this), k_tt_multiples8, dim3(cdiv((uint64_t)2 * M0 * TT8_WINDOWS, 256)), dim3(256), bases8.as<ge_ext>(), table.as<ge_pniels>(), 2 * M0 * TT8_WINDOWS);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+        } catch (...) {   // a table that was not built is not published: give its memory and its share of the budget back (as odd_ensure does)
+            (void)hipStreamSynchronize(st); bases8.release(); table.release(); table_bytes_add(shared->device, -(int64_t)bytes);
+            throw;
+        }
         bases8.release();
         shared->wide[M0] = table;                                               // (its bytes were reserved above)
         return table.as<ge_pniels>();
@@ -398,7 +404,7 @@ struct Engine::Impl {
     struct SlabDev { DevBuf d; hipStream_t copy_st = nullptr; std::vector<hipEvent_t> ev; };
     std::vector<std::unique_ptr<SlabDev>> slab_dev;         // device side of each slab: the uploaded draws, the copy stream, one event per block
     int last_chain_cpu = -1;
-    bool test_fail_upload = false;
+    int test_fail_upload = 0;       // test hooks: 1 the next stream's upload reports an error, 2 its copies are silently dropped
     static void blind_stop(const std::shared_ptr<BlindStream> &b) {       // returns once the worker no longer touches b's slab
         b->stop.store(true, std::memory_order_relaxed);
     }
@@ -491,12 +497,12 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (cfg.table_budget_gb < 0 || cfg.table_budget_gb > 4096) throw std::invalid_argument("bpg_config.table_budget_gb: 0 (default) .. 4096");
     if (cfg.chain_workers > 64) throw std::invalid_argument("bpg_config.chain_workers: 0 (default), 1..64");
     if (cfg.chain_lanes > 8) throw std::invalid_argument("bpg_config.chain_lanes: 0 (default), 1..8");
-    if (cfg.blocking_sync > 2) throw std::invalid_argument("bpg_config.blocking_sync: 0 (default), 1 (blocking) or 2 (spin)");
+    if (cfg.blocking_sync < -1 || cfg.blocking_sync > 2) throw std::invalid_argument("bpg_config.blocking_sync: -1 (environment, else spin), 0 (spin), 1 (blocking)");
     // What the host chose (bpg_config): the struct first, then the environment variable, then the profile's default.  Everything is settled
     // in this local Impl before the first HIP call, so a bad knob costs nothing and leaks nothing.
     std::unique_ptr<Impl> K(new Impl());
-    uint32_t blocking = cfg.blocking_sync;                      // 0 unset, 1 blocking, 2 spin
-    if (blocking == 0 && env_present("BPG_SYNC_BLOCKING")) blocking = env_int_strict("BPG_SYNC_BLOCKING", 0, 1) ? 1u : 2u;
+    int blocking = cfg.blocking_sync == 2 ? 0 : cfg.blocking_sync;          // -1 unset, 0 spin, 1 blocking (2: what one header revision called spin)
+    if (blocking < 0 && env_present("BPG_SYNC_BLOCKING")) blocking = env_int_strict("BPG_SYNC_BLOCKING", 0, 1) ? 1 : 0;
     uint32_t profile = cfg.profile;
     if (profile == 0) { if (const char *e = std::getenv("BPG_PROFILE")) profile = (!std::strcmp(e, "serving") || !std::strcmp(e, "2")) ? 2u : 1u; else profile = 1u; }
     // one-shot (the default of a bare bpg_ctx_create): width-6 NAF fold tables on whole scalars (3.0 GB at 2^20, built in 7 ms), no 8-bit tail
@@ -559,6 +565,7 @@ void Engine::init_device() {
                                    0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82, 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
     uint8_t h[64]; sha3_512_host(h, Bc, 32);
     impl_->small_in.ensure(4096); impl_->bases.ensure(3 * sizeof(ge_niels));
+    impl_->stale_flag.ensure(64); HIPCHK(hipMemsetAsync(impl_->stale_flag.p, 0, 64, impl_->st));
     HIPCHK(hipMemcpyAsync(impl_->small_in.p, h, 64, hipMemcpyHostToDevice, impl_->st));
     hipLaunchKernelGGL(k_init_bases, dim3(1), dim3(64), 0, impl_->st, impl_->small_in.as<uint32_t>(), impl_->bases.as<ge_niels>());
     HIPCHK(hipGetLastError());
@@ -575,14 +582,17 @@ void Engine::init_device() {
 
 Engine::~Engine() {
     if (!impl_) return;
+    // order: (1) no host thread of ours issues work for this context any more (the chain threads have left its streams), (2) everything this
+    // context queued has finished - the engine stream AND the slabs' copy streams, whose uploads read the pinned slabs - (3) only then memory goes
     impl_->chain_shutdown();
     (void)hipSetDevice(device_);
     (void)hipStreamSynchronize(impl_->st);
+    for (auto &sd : impl_->slab_dev) if (sd->copy_st) (void)hipStreamSynchronize(sd->copy_st);
     DevBuf *bufs[] = {&impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
                       &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->stale_flag, &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
@@ -1309,7 +1319,7 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     TranscriptRng rng = T.build_rng(v_blinding, seed);
     for (int k = 0; k < 3; k++) b->first[k] = rng.random_scalar();
     b->max_draws = ((2 * max_multipliers + BS::SNAP - 1) / BS::SNAP) * BS::SNAP;
-    b->inject_fail = I.test_fail_upload; I.test_fail_upload = false;
+    b->inject_fail = I.test_fail_upload; I.test_fail_upload = 0;
     // pinned slab: one that no alive stream owns; its previous owner must have left it (its uploads were synchronised by the prove() that used it)
     if (I.h_blind.size() < max_alive) { I.h_blind.resize(max_alive); I.slab_owner.resize(max_alive); while (I.slab_dev.size() < max_alive) I.slab_dev.emplace_back(std::make_unique<Impl::SlabDev>()); }
     int slot = -1;
@@ -1327,17 +1337,23 @@ void Engine::blinding_begin(const Transcript &after_commitments, const std::vect
     I.h_blind[slot].ensure(b->max_draws * 64);
     sd.d.ensure(b->max_draws * 64);
     while (sd.ev.size() < b->max_draws / BS::UP + 1) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sd.ev.push_back(e); }
-    // The device slab changes owner here.  What keeps this proof from reading the previous owner's draws is BlindStream::err: an upload that
-    // fails is recorded BEFORE its block is published and prove() refuses the stream.  (Round 3 also overwrote the slab with a constant first;
-    // nothing ever checked for that constant, a proof built from it would be no more zero-knowledge than one built from stale draws, and it was
-    // a 128 MB memset per 2^20 proof on the copy stream: removed.)
+    // The device slab changes owner here.  Two things keep this proof from reading the previous owner's draws: BlindStream::err - an upload that
+    // fails is recorded BEFORE its block is published and prove() refuses the stream - and a canary against a copy that is dropped WITHOUT an error:
+    // the first draw of every block is overwritten with a pattern here (1 KB of stores for a 2^20 proof, on the copy stream, ahead of the uploads),
+    // k_sc_from_wide raises stale_flag on a draw that still reads as the pattern, and prove() checks the flag before the proof leaves it.  (Round 3
+    // overwrote the whole slab - a 128 MB memset per 2^20 proof - with a constant nothing ever checked for.)
+    {
+        const uint32_t nblk = (uint32_t)((b->max_draws + BS::UP - 1) / BS::UP);        // the last block may be a partial one
+        if (nblk) hipLaunchKernelGGL(k_blind_poison, dim3(cdiv((uint64_t)nblk * 16, 256)), dim3(256), 0, sd.copy_st, sd.d.as<uint32_t>(), nblk, (uint32_t)BS::UP);
+        HIPCHK(hipGetLastError());
+    }
     b->raw = I.h_blind[slot].as<uint8_t>();
     b->device = device_; b->copy_st = sd.copy_st; b->d_raw = sd.d.as<uint8_t>(); b->ev = &sd.ev;
     // how a drawn block reaches the device (called on the chain thread; host/chain.hpp publishes the block afterwards): an asynchronous copy on the
     // slab's own copy stream, then the block's event; the threads of a pool serve contexts of different devices, hence the hipSetDevice
     b->upload = [](BlindStream &bs, uint64_t from, uint64_t to, uint64_t k) -> int {
         hipError_t e = hipSetDevice(bs.device);
-        if (e == hipSuccess) e = hipMemcpyAsync(bs.d_raw + 64 * from, bs.raw + 64 * from, (to - from) * 64, hipMemcpyHostToDevice, static_cast<hipStream_t>(bs.copy_st));
+        if (e == hipSuccess && bs.inject_fail != 2) e = hipMemcpyAsync(bs.d_raw + 64 * from, bs.raw + 64 * from, (to - from) * 64, hipMemcpyHostToDevice, static_cast<hipStream_t>(bs.copy_st));
         if (e == hipSuccess) e = hipEventRecord((*static_cast<std::vector<hipEvent_t> *>(bs.ev))[k], static_cast<hipStream_t>(bs.copy_st));
         return (int)e;
     };
@@ -1376,10 +1392,12 @@ void Engine::set_chain_lanes(uint32_t n) {
     impl_->chain_lanes = n;
 }
 void Engine::blinding_cancel() { impl_->blind_cancel(); }
-void Engine::test_fail_next_upload() { impl_->test_fail_upload = true; }
+void Engine::test_fail_next_upload() { impl_->test_fail_upload = 1; }
+void Engine::test_drop_next_upload() { impl_->test_fail_upload = 2; }
 uint64_t Engine::table_bytes() const { return table_bytes_held(device_); }
 
 int Engine::chain_cpu() const { return impl_->last_chain_cpu; }
+bool Engine::last_shared_variants() const { return impl_->shared_now; }
 
 std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::vector<Scalar> &v_blinding,
                                    const uint8_t rng_seed[32], uint32_t flags, ProveTimings *tm) {
@@ -1500,7 +1518,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             }
             if (bs->uploaded_blocks.load(std::memory_order_acquire) < nblk) throw DeviceError("the blinding stream ended before its draws were uploaded");
             for (uint64_t k = 0; k < nblk; k++) HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
-            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw), sL, (uint32_t)(2 * n));
+            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw), sL, (uint32_t)(2 * n), I.stale_flag.as<uint32_t>());
         } else
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
@@ -1516,11 +1534,11 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
                     throw DeviceError(std::string("upload of the blinding draws failed: ") + hipGetErrorString((hipError_t)uerr));
                 }
                 HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
-                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt);
+                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt, I.stale_flag.as<uint32_t>());
             } else {
                 rng.fill_draws64(raw + 64 * i, cnt);
                 HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
-                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt);
+                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt, I.stale_flag.as<uint32_t>());
             }
             if (!merged && i + cnt < 2 * n) launch_pieces(i + cnt);
         }
@@ -1611,7 +1629,13 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     scm h_t[6]; std::vector<scm> h_wV(m ? m : 1);
     HIPCHK(hipMemcpyAsync(h_t, I.red_out.p, 6 * sizeof(scm), hipMemcpyDeviceToHost, st));
     if (m) HIPCHK(hipMemcpyAsync(h_wV.data(), wV, m * sizeof(scm), hipMemcpyDeviceToHost, st));
+    uint32_t *h_stale = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 32768);
+    HIPCHK(hipMemcpyAsync(h_stale, I.stale_flag.p, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (*h_stale) {   // a blinding draw was read from a slab position no upload of this proof wrote (k_sc_from_wide): nothing of this proof may leave
+        HIPCHK(hipMemsetAsync(I.stale_flag.p, 0, 4, st));
+        throw DeviceError("a blinding draw was read before it was uploaded (stale device slab): proof withheld");
+    }
     Scalar t[7], tb[7];
     for (int k = 0; k < 6; k++) t[k + 1] = from_scm(h_t[k]);
     tb[1] = rng.random_scalar(); tb[3] = rng.random_scalar(); tb[4] = rng.random_scalar(); tb[5] = rng.random_scalar(); tb[6] = rng.random_scalar();

@@ -27,7 +27,7 @@ struct EngineConfig {
     double table_budget_gb = 0;     // cumulative HBM the precomputed generator multiples of this device may take (BPG_TABLE_GB); 0 unset
     uint32_t chain_workers = 0;     // 0 unset (BPG_CHAIN_WORKERS, else 1)
     uint32_t chain_lanes = 0;       // 0 unset (BPG_CHAIN_LANES, else 1)
-    uint32_t blocking_sync = 0;     // 0 unset (BPG_SYNC_BLOCKING=1/0, else spin), 1 blocking waits, 2 spin waits
+    int32_t blocking_sync = -1;     // -1 unset (BPG_SYNC_BLOCKING=1/0, else spin), 1 blocking waits, 0 (or 2) spin waits
     std::string gens_cache_dir;     // empty unset (BPG_GENS_CACHE_DIR, else no cache)
 };
 
@@ -82,7 +82,9 @@ public:
     void attach_chain_pool(ChainPool *pool, uint32_t max_streams);
     void set_chain_lanes(uint32_t n);        // streams each chain thread draws in lockstep (1..8; eight sponges in the lanes of ZMM registers)
     void test_fail_next_upload();   // test hook (bpg_test_fail_next_upload)
+    void test_drop_next_upload();   // test hook (bpg_test_drop_next_upload): the copies of the next stream are skipped without an error
     uint64_t table_bytes() const;   // precomputed generator multiples held on this device by the process
+    bool last_shared_variants() const;   // did the last prove()/verify() on this context take the shared-device kernel variants
     int chain_cpu() const;      // host core the chain worker last drew a stream on (-1: none yet); diagnostics for bench.py
     void test_fe_ops(int op, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);   // unit-test hook (k_test_fe)
     // Verifier::verify on a resident (assignment-free) circuit. transcript: state after Verifier::new + every "V" append.

@@ -91,18 +91,6 @@ __global__ void __launch_bounds__(256) k_normalize_niels(const ge_ext *__restric
     }
 }
 
-__global__ void __launch_bounds__(64) k_compress(const ge_ext *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    ge_compress(out + 32 * (size_t)i, in[i]);
-}
-// out = in[0] + .. + in[count-1]  (a handful of partial MSM results)
-__global__ void __launch_bounds__(64) k_sum_points(const ge_ext *__restrict__ in, uint32_t count, ge_ext *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ge_ext acc = count ? in[0] : ge_identity();
-    for (uint32_t k = 1; k < count; k++) acc = ge_add(acc, in[k]);
-    *out = acc;
-}
 __global__ void __launch_bounds__(64) k_compress_niels(const ge_niels *__restrict__ in, uint8_t *__restrict__ out, uint32_t count) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;

@@ -13,14 +13,29 @@ __global__ void __launch_bounds__(256) k_sc_from_bytes(const uint32_t *__restric
     w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
     out[i] = sc_from_words(w);
 }
-// 64-byte TranscriptRng draws -> scalars (Scalar::random = from_bytes_mod_order_wide)
-__global__ void __launch_bounds__(256) k_sc_from_wide(const uint32_t *__restrict__ in, scm *__restrict__ out, uint32_t count) {
+// 64-byte TranscriptRng draws -> scalars (Scalar::random = from_bytes_mod_order_wide).
+// Canary: the device slab the draws of a proof are uploaded into is reused from proof to proof; when it changes owner the first draw of every
+// uploaded block is overwritten with BLIND_POISON words (k_blind_poison).  A draw that still reads as poison was never uploaded - a dropped copy that
+// reported no error - and the scalar would be built from something the host did not draw (in the worst case the previous proof's s_L, s_R, which
+// together with this proof would leak the witness): it raises *stale, and prove() refuses to emit the proof.  A real draw equals the pattern with
+// probability 2^-512.
+#define BLIND_POISON 0xa5c3a5c3u
+__global__ void __launch_bounds__(256) k_blind_poison(uint32_t *__restrict__ raw, uint32_t nblocks, uint32_t draws_per_block) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nblocks * 16u) return;
+    raw[(size_t)(t >> 4) * draws_per_block * 16u + (t & 15u)] = BLIND_POISON;
+}
+__global__ void __launch_bounds__(256) k_sc_from_wide(const uint32_t *__restrict__ in, scm *__restrict__ out, uint32_t count, uint32_t *__restrict__ stale) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     uint32_t w[16];
     const uint4 *src = reinterpret_cast<const uint4 *>(in + 16 * (size_t)i);
 #pragma unroll
     for (int k = 0; k < 4; k++) { uint4 q = src[k]; w[4 * k] = q.x; w[4 * k + 1] = q.y; w[4 * k + 2] = q.z; w[4 * k + 3] = q.w; }
+    uint32_t diff = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) diff |= w[k] ^ BLIND_POISON;
+    if (diff == 0) atomicOr(stale, 1u);
     out[i] = sc_from_wide_words(w);
 }
 // BPG_FLAG_EXPANDED_BLINDING (include/bpg.h): scalar j = SHAKE256("bpg blinding v1" || K || le64(j))[0..64) mod l, one Keccak-f[1600]
@@ -64,14 +79,6 @@ __global__ void __launch_bounds__(256) k_blind_expand(const BlindHead head, scm 
     for (int k = 0; k < 8; k++) { w[2 * k] = (uint32_t)a[k]; w[2 * k + 1] = (uint32_t)(a[k] >> 32); }
     out[j] = sc_from_wide_words(w);
 }
-__global__ void __launch_bounds__(256) k_sc_to_bytes(const scm *__restrict__ in, uint32_t *__restrict__ out, uint32_t count) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    uint32_t w[8]; sc_to_words(w, in[i]);
-#pragma unroll
-    for (int k = 0; k < 8; k++) out[8 * (size_t)i + k] = w[k];
-}
-
 // out[i] = base^i for i < count (Montgomery form). Thread t walks i = t, t+T, ... multiplying by base^T; T = 2^lgT.
 __global__ void __launch_bounds__(256) k_exp_table(scm base, scm *__restrict__ out, uint32_t count, uint32_t lgT) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

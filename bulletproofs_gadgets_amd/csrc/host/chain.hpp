@@ -44,14 +44,14 @@ struct BlindStream {
     // first error of this stream's uploads (0 = none), stored BEFORE uploaded_blocks is published: the device slab is reused from proof to
     // proof, so a block that was not copied would hand prove() the previous proof's draws - prove() checks and refuses
     std::atomic<int> err{0};
-    bool inject_fail = false;                                   // bpg_test_fail_next_upload
+    int inject_fail = 0;                                        // test hooks: 1 = bpg_test_fail_next_upload (an upload reports an error), 2 = bpg_test_drop_next_upload (the copy is skipped, no error)
     void note(int e) { if (e != 0) { int want = 0; err.compare_exchange_strong(want, e, std::memory_order_release); } }
     // draws [up, to) -> device; returns the new `up`
     uint64_t hand_over(uint64_t up, uint64_t to) {
         if (to <= up) return up;
         const uint64_t k = up / UP;
         note(upload ? upload(*this, up, to, k) : 0);
-        if (inject_fail) note(999);                             // hipErrorUnknown
+        if (inject_fail == 1) note(999);                        // hipErrorUnknown
         uploaded_blocks.store(k + 1, std::memory_order_release);
         return to;
     }

@@ -178,7 +178,10 @@ public:
     void flush_commitments();
     // TEST HOOK (include/bpg.h bpg_test_prover_stub_commitments): commitments become 32 hash bytes of (v, blinding) made on the host - NOT group
     // elements - so that the file drivers' parsers and the gadget assembly can be fuzzed under sanitizers without a device; prove() stays refused
-    void test_stub_commitments() { stub_commitments_ = true; }
+    void test_stub_commitments() {
+        if (engine_) throw std::invalid_argument("stub commitments are for device-less provers only (a prover with an engine makes real Pedersen commitments)");
+        stub_commitments_ = true;
+    }
     size_t num_flushed() const { return flushed_; }
     const uint8_t *commitment(size_t i) const { return &V_[32 * i]; }
 

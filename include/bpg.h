@@ -69,13 +69,19 @@ typedef struct {
     const uint8_t *coef;          /* ncoef x 32 */
 } bpg_r1cs_instance;
 
-typedef struct {                  /* milliseconds; filled when a non-NULL pointer is passed to a prove call */
+/* milliseconds; filled when a non-NULL pointer is passed to a prove call.  FROZEN at nine doubles (72 bytes): the library writes exactly these and
+ * the struct never grows (a caller-owned struct without a size field cannot).  Whether a proof took the shared-device kernel variants is reported by
+ * bpg_ctx_last_shared_variants() and in bpg_profile_report's "_schedule". */
+typedef struct {
     double rng_host, msm_aiao, msm_s, poly, ipa, total, ipa_msm, ipa_fold, ipa_sync;
-    double shared_variants;       /* 1.0: the proof took the kernel variants for a shared device (another prove() was in flight on the device when this one
-                                     was entered; decided once per proof) - replay a failing proof with BPG_FOLD_ADAPT=2 (always) or 0 (never) */
 } bpg_timings;
 
 /* ---------------------------------------------------------------------------------------------------- PART 1: hot path */
+/* ABI version of this header.  Rules: structs the CALLER allocates either carry a struct_size (bpg_config: fields are only ever added at the end and
+ * read when struct_size covers them) or are frozen (bpg_timings, bpg_r1cs_instance, bpg_batch_item, bpg_term, bpg_lc); a field never changes type or
+ * meaning; BPG_ABI_VERSION grows with every addition.  A host checks bpg_abi_version() >= the BPG_ABI_VERSION it was compiled against. */
+#define BPG_ABI_VERSION 5u
+uint32_t bpg_abi_version(void);
 const char *bpg_strerror(bpg_status s);
 const char *bpg_last_error(void);                                /* message of the calling thread's last failure */
 
@@ -96,9 +102,10 @@ typedef struct {
                                     not fit is replaced by the next smaller table set, in the end by kernels that need none; 0 = profile default */
     uint32_t chain_workers;      /* bpg_ctx_set_chain_workers at creation (BPG_CHAIN_WORKERS); 0 = default 1 */
     uint32_t chain_lanes;        /* bpg_ctx_set_chain_lanes at creation (BPG_CHAIN_LANES); 0 = default 1 */
-    uint32_t blocking_sync;      /* 1: host threads sleep in stream waits (hipDeviceScheduleBlockingSync; device-wide, first context of the process
-                                    decides) - for hosts that run many proving threads beside their chain threads; 2: spin; 0 = BPG_SYNC_BLOCKING
-                                    (1 / 0) if set, else spin */
+    int32_t blocking_sync;       /* 1: host threads sleep in stream waits (hipDeviceScheduleBlockingSync; device-wide, first context of the process
+                                    decides) - for hosts that run many proving threads beside their chain threads; 0 (and 2, which one revision of this
+                                    header used for it): spin; -1 = BPG_SYNC_BLOCKING (1 / 0) if set, else spin.  A zeroed struct therefore spins, which
+                                    is also what an unset environment gives */
     const char *gens_cache_dir;  /* directory of the on-disk generator cache (BPG_GENS_CACHE_DIR); NULL = no cache */
 } bpg_config;
 int32_t bpg_device_count(void);          /* AMD GPUs visible to the process (0: none - every bpg_ctx_create then fails with BPG_ERR_DEVICE) */
@@ -171,8 +178,14 @@ bpg_status bpg_test_fe_ops(bpg_ctx *ctx, int32_t op, uint64_t n, const uint8_t *
 /* test hook: the next blinding stream started on ctx (bpg_blinding_begin) records a failed upload of its first block, as a failing hipMemcpyAsync
  * would: the prove that adopts it must fail with BPG_ERR_DEVICE instead of reading a stale device slab */
 bpg_status bpg_test_fail_next_upload(bpg_ctx *ctx);
+/* test hook: the copies of the next blinding stream started on ctx are skipped WITHOUT an error (a dropped DMA): the device slab keeps the pattern its
+ * blocks were marked with when the slab changed owner, the conversion kernel notices, and the prove that adopts the stream fails with BPG_ERR_DEVICE */
+bpg_status bpg_test_drop_next_upload(bpg_ctx *ctx);
 /* diagnostics: bytes of precomputed generator multiples (fold tables + wide tail tables) this process holds on the context's device */
 uint64_t bpg_table_bytes(bpg_ctx *ctx);
+/* diagnostics: 1 when the last bpg_r1cs_prove* / bpg_prover_prove on ctx took the kernel variants for a shared device (another prove() was in flight on the
+ * device when it was entered; decided once per proof), else 0 - replay a failing proof with BPG_FOLD_ADAPT=2 (always) or 0 (never) */
+int32_t bpg_ctx_last_shared_variants(bpg_ctx *ctx);
 /* test hook: compress(sum s_i*G[first+i] + t_i*H[first+i]) through the bucket-method MSM kernels */
 bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]);
 
@@ -196,7 +209,8 @@ bpg_status bpg_prover_new(bpg_ctx *ctx, bpg_transcript *t, bpg_prover **out);   
 void bpg_prover_free(bpg_prover *p);
 /* test hook: from now on the commitments of p are 32 hash bytes of (value, blinding) made on the host - NOT group elements - so that a device-less
  * prover (bpg_prover_new with ctx = NULL) can run a file driver's parsing and gadget assembly under sanitizers / a fuzzer; bpg_prover_prove stays
- * refused (BPG_ERR_DEVICE) */
+ * refused (BPG_ERR_DEVICE).  Refused with BPG_ERR_INVALID_ARGUMENT on a prover that HAS a device context: such a prover never hands out anything
+ * but Pedersen commitments */
 bpg_status bpg_test_prover_stub_commitments(bpg_prover *p);
 bpg_status bpg_prover_commit(bpg_prover *p, const uint8_t v[32], const uint8_t blind[32], uint8_t com_out[32], uint32_t *var_out);
 bpg_status bpg_prover_commit_many(bpg_prover *p, uint64_t k, const uint8_t *v, const uint8_t *blind, uint8_t *coms_out, uint32_t *vars_out);

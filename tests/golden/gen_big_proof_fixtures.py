@@ -3,6 +3,8 @@
     cfg4_merkle512   the reference's own 2^20 circuit (src/merkle_tree/merkle_tree_gadget.rs:473-545: 512 x leaf W1, n = 993,384), 2 seeds
     merkle256_seed5  a full 256-leaf tree with seeded leaves, N = 2^19 (the circuit of test_fold_profiles_agree_at_half_a_million_multipliers)
     cfg3_mimc67      BASELINE.json config 3: HASH over 2,130 bytes, 67 absorbed blocks, N = 2^16
+    cfg4b_path20     SURVEY.md section 8 cfg 4b: BASELINE.json's "depth 20" read literally - one Merkle authentication path through the FILE driver
+                     (workloads.merkle_path_files -> cli.prover(assemble_only)), n = 39,852, N = 2^16
 for all four encoding dialects.  The circuits are assembled by the product's HOST code (workloads.py on an assembly-only prover); every Pedersen
 commitment is made by the oracle (O.pedersen_commit) and handed in through bpg_prover_commit_precomputed, so the recorded transcript state is
 the oracle's too.  One oracle prove per distinct transcript (flags 0 and NO_1PHASE_DOMSEP); the COMPACT encodings are the same proofs with the
@@ -18,7 +20,7 @@ sys.path.insert(0, os.path.dirname(HERE)); sys.path.insert(0, os.path.dirname(os
 
 SEEDS = [bytes(range(32)), hashlib.sha256(b"bpg proof fixture").digest()]
 # circuit -> seeds proved at each of the two transcripts
-PLAN = {"cfg4_merkle512": SEEDS, "merkle256_seed5": SEEDS[:1], "cfg3_mimc67": SEEDS[:1]}
+PLAN = {"cfg4_merkle512": SEEDS, "merkle256_seed5": SEEDS[:1], "cfg3_mimc67": SEEDS[:1], "cfg4b_path20": SEEDS[:1]}
 
 
 def oracle_prover_class():
@@ -55,7 +57,27 @@ def build(name, ctx=None):
         return workloads.merkle_full_tree(ctx, leaves=256, seed=5, **kw)
     if name == "cfg3_mimc67":
         return workloads.mimc_preimage(ctx, nbytes=2130, seed=0, **kw)
+    if name == "cfg4b_path20":
+        return path20(ctx, **kw)
     raise KeyError(name)
+
+
+def path20(ctx, prover_cls=None):
+    """cfg 4b through the file driver, assembled but not proved.  The transcript label is the NAME argument of the driver (prover.rs:49-52): the files
+    are written to a scratch directory and the driver runs there under the fixed relative name "path20"."""
+    import tempfile
+    from bulletproofs_gadgets_amd import cli, workloads
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        try:
+            n = workloads.merkle_path_files("path20", depth=20)
+            p, t = cli.prover("path20", ctx=ctx, seed=b"cfg4b", rng_seed=bytes(32), quiet=True, two_pass=False, prover_cls=prover_cls, assemble_only=True)
+        finally:
+            os.chdir(cwd)
+    assert p.get_num_multiplications() == n == 39852
+    coms = [p.commitment(i) for i in range(p.num_committed())]
+    return workloads.Assembled(p, t, coms, 1 << 16, None)
 
 
 def compact_of(proof14):

@@ -107,7 +107,14 @@ def test_depth20_merkle_path_cfg4b(ctx, tmp_path):
     v, tv = cli.assemble_verifier(stem)
     vi = v.instance()
     oc = O.FlatCircuit(vi.n, vi.m, None, None, None, vi.row_ptr, vi.term_var, vi.term_coef, vi.coef)
-    assert O.verify(O.Gens(65536), tv.state, oc, vi.commitments, proof) == 0
+    gens = O.Gens(65536)
+    assert O.verify(gens, tv.state, oc, vi.commitments, proof) == 0
+    # the oracle PROVER on the same statement (the driver's assembly with the GPU's commitments, the same blindings and seed) gives the same bytes
+    pa, ta = cli.prover(stem, ctx=ctx, seed=b"cfg4b", rng_seed=bytes(32), quiet=True, two_pass=False, assemble_only=True)
+    pi = pa.instance()
+    rc, want, _ = O.prove(gens, ta.state, O.FlatCircuit(pi.n, pi.m, pi.aL, pi.aR, pi.aO, pi.row_ptr, pi.term_var, pi.term_coef, pi.coef), pi.v_blinding,
+                          bytes(32), O.FLAG_FAST_MSM)
+    assert rc == 0 and want == proof
     # a wrong sibling must make the prover's own circuit unsatisfied -> the proof does not verify
     lines = open(stem + ".inst").read().splitlines()
     lines[7] = lines[7][:-2] + ("00" if lines[7][-2:] != "00" else "01")

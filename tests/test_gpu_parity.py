@@ -1098,6 +1098,15 @@ def test_failed_upload_of_blinding_draws_is_refused(ctx):
     assert res.prove(state, inst.v_blinding, seed, 0)[0] == good          # drawn inside the call
     ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
     assert res.prove(state, inst.v_blinding, seed, 0)[0] == good
+    # a copy that is dropped WITHOUT an error: the slab still holds the marks it got when it changed owner; the conversion kernel sees them and the
+    # proof is withheld (never built from what the slab held before)
+    assert bpg.lib().bpg_test_drop_next_upload(ctx._h) == 0
+    ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
+    with pytest.raises(bpg.BpgError) as e:
+        res.prove(state, inst.v_blinding, seed, 0)
+    assert e.value.status == 7 and "stale" in str(e.value)
+    ctx.blinding_begin(state, inst.v_blinding, seed, inst.n)
+    assert res.prove(state, inst.v_blinding, seed, 0)[0] == good          # and the context goes on
     res.free()
 
 

@@ -373,12 +373,17 @@ def test_config_struct_matches_the_header_and_pool_api_without_a_gpu(tmp_path):
     import ctypes as C
     import subprocess
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bpg.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bpg_config), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "bpg.h"\nint main(void) { printf("%zu %u\\n", sizeof(bpg_timings), BPG_ABI_VERSION); printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bpg_config), '
                    'offsetof(bpg_config, struct_size), offsetof(bpg_config, profile), offsetof(bpg_config, table_budget_gb), offsetof(bpg_config, chain_workers), '
                    'offsetof(bpg_config, chain_lanes), offsetof(bpg_config, blocking_sync), offsetof(bpg_config, gens_cache_dir)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", str(O.ROOT / "include"), "-o", str(exe), str(src)])
     want = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    # the caller-owned structs without a size field are frozen: bpg_timings is nine doubles, here and in the binding; the library says which ABI it speaks
+    assert want[0] == 72 == C.sizeof(bpg.Timings)
+    bpg.lib().bpg_abi_version.restype = C.c_uint32
+    assert bpg.lib().bpg_abi_version() == want[1] >= 5
+    want = want[2:]
     got = [C.sizeof(bpg.Config)] + [getattr(bpg.Config, f).offset for f, _ in bpg.Config._fields_]
     assert got == want, (got, want)
     cfg = bpg.make_config("serving", table_budget_gb=12.5, chain_workers=3, chain_lanes=4, blocking_sync=True, gens_cache_dir="/tmp/x")
