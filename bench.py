@@ -32,6 +32,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 METRIC = "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU"
+SWEEPS = ("k_bucket_sorted", "k_bucket_chunks")            # the bucket sweep's two shapes (csrc/hip/k_msm.cuh): shared device / proof alone
 ENGINE = {"profile": "serving", "blocking_sync": True}       # bpg_config of every engine context (include/bpg.h bpg_ctx_create_ex)
 
 
@@ -45,6 +46,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--leaves", type=int, default=512, help="leaves of the full MiMC Merkle tree (512 = the reference's 2^20 circuit)")
+    ap.add_argument("--leaf-seed", type=int, default=None, help="leaves of the tree: unset = the reference's own instance (512 times the SAME leaf, merkle_tree_gadget.rs:476-520: every "
+                    "node of a level then carries the same values, and the equal-scalar merging of A_I / A_O collapses 2.98 M terms into ~35 k); an integer = distinct seeded leaves "
+                    "(only the wiring of a MiMC round repeats a value: 43 %% of A_I's terms merge, none of A_O's)")
     ap.add_argument("--baseline-leaves", type=int, default=512, help="leaves of the CPU-baseline tree (512 = the headline circuit itself, about 150 s on one core; "
                     "64 -> N = 2^17, about 17 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -72,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--in-flight-only", action="store_true", help="only the throughput leg (for profiling the concurrent kernel mix)")
     ap.add_argument("--profile", choices=("serving", "oneshot"), default="serving", help="bpg_config.profile of every engine context: serving (the headline: a long-lived "
                     "prover, 51.5 GB of fold tables per device) or oneshot (what a bare bpg_ctx_create gives a drop-in caller: 3 GB of tables)")
+    ap.add_argument("--plan-only", action="store_true", help="print what --gpus N would do on this node - per rank: device, NUMA node, CPU set, chain-pool lanes, expected HBM and "
+                    "pinned host memory - from the planner the real run uses, WITHOUT touching a GPU; a node with fewer cards is planned on an assumed 2-socket topology")
     ap.add_argument("--no-one-shot-leg", action="store_true", help="skip `value_one_shot` (the timed steps once more under the one-shot profile, in a child process)")
     return ap.parse_args(argv)
 
@@ -184,6 +190,113 @@ def plan_chain_pool(cores_per_rank, n_streams, reserve=2):
         share = min(8, -(-(rest - sum(lanes[singles:])) // (k - j)))
         lanes.append(max(1, share))
     return lanes                                              # sum(lanes) < n_streams only when 8 * T < n_streams: the remaining chains queue
+
+
+# ------------------------------------------------------------------------------------------------ memory model and the plan of a node (--plan-only)
+def memory_model(n, N, q, m, profile, streams, nnz=None, merged_terms=0):
+    """Bytes ONE rank holds in HBM and in pinned host memory at the headline arrangement: an analytic mirror of the allocations of csrc/engine.hip (the buffer
+    names are the engine's), checked against what the card reports in the bench line (`hbm_in_use` beside `hbm_model`).  n multipliers padded to N, q
+    constraints, m commitments; `streams` proving streams (engine contexts) with a resident copy of the circuit and two blinding slabs each."""
+    S, P_NIELS, P_EXT, P_PN = 32, 96, 128, 128
+    nnz = nnz if nnz is not None else 3 * q                     # MiMC circuits: about three terms per constraint
+    W, nb = 16, 1 << 15                                         # shared-device windows: 16 bits (17 x 2^14 for a proof alone: the same bytes within 6 %)
+    al = lambda x: (x + 255) & ~255
+
+    def msm_arena(total, live, sorted_sweep=True):
+        mub = live * W
+        slots = ((mub // 64) + (mub // 256) + 1) * P_EXT if sorted_sweep else -(-mub // 34) * 2 * P_EXT
+        return max(al(total * W * 2) + al(live * W * 4), al(slots)) + al(live * W * 4)
+    # device-wide, shared by the contexts of the process: [G | H] and the odd multiples of the first fold
+    gens = 2 * N * P_NIELS
+    tables = (255 if profile == "serving" else 15) * gens
+    # per proving stream
+    calls = [(3 * n + 2, 3 * n + 2 - merged_terms), (2 * n + 1, 2 * n + 1), (2 * N + 2, 2 * N + 2)]      # A_I + A_O, the largest piece of S, a round of the first fold group
+    arena = max([msm_arena(t, l) for t, l in calls] + [al((2 * 4096 + 1) * 64 * P_EXT) + (2 * 4096 + 1) * 64 * 8 * P_PN, (3 * n + m + 1 + q + 2 + N) * S])
+    buckets = 3 * W * nb * P_EXT                                # up to three sums in one launch (A_I, A_O, S when the chain was drawn ahead)
+    partial = 2 * 3 * W * (nb // 8) * P_EXT
+    tiles = -(-2 * n // 4096)
+    sortws = 3 * (3 * W * 256 * tiles + 1) * 4 + 3 * W * nb * 4
+    prove = 2 * n * S + 3 * N * S + 4 * (N // 2) * S + 3 * (N // 2) * P_NIELS + 2 * (N >> 3) * P_EXT      # s_L|s_R, y^-i, l, r, expanded scalars, folded tables A|B, fold scratch
+    slabs = 2 * (2 * n * 64)
+    circuit = 3 * n * S + (3 * n + m + 2) * 8 + 2 * nnz * 4
+    per_stream = arena + buckets + partial + sortws + prove + slabs + circuit
+    runtime = 1.2e9                                             # HIP runtime, code objects, torch: measured on an idle context
+    hbm = gens + tables + streams * per_stream + runtime
+    pinned = streams * (2 * (2 * n * 64) + (16 << 20) + (1 << 20))      # two blinding slabs, the upload bounce slots, window-sum slots
+    return {"hbm_GB": hbm / 1e9, "pinned_host_GB": pinned / 1e9, "per_stream_GB": per_stream / 1e9, "tables_GB": (gens + tables) / 1e9,
+            "arena_GB": arena / 1e9, "streams": streams, "profile": profile}
+
+
+def discover_topology(gpus):
+    """The node as sysfs shows it, WITHOUT touching a GPU: AMD display / accelerator functions with their NUMA node, the cores of every node, host RAM,
+    the cgroup CPU quota.  None when fewer than `gpus` devices are visible (the build container: none)."""
+    devs = []
+    try:
+        for d in sorted(pathlib.Path("/sys/bus/pci/devices").iterdir()):
+            try:
+                if (d / "vendor").read_text().strip() != "0x1002":
+                    continue
+                cls = (d / "class").read_text().strip()
+                if not (cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200")):
+                    continue
+                node = int((d / "numa_node").read_text())
+                devs.append({"pci": d.name, "numa_node": max(node, 0)})
+            except Exception:       # noqa: BLE001
+                continue
+    except Exception:       # noqa: BLE001
+        return None
+    if len(devs) < gpus:
+        return None
+    nodes = {}
+    for nd in sorted(pathlib.Path("/sys/devices/system/node").glob("node[0-9]*")):
+        cpus = _cpulist((nd / "cpulist").read_text())
+        cores = set()
+        for c in cpus:
+            try:
+                sib = _cpulist(pathlib.Path("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read_text())
+            except Exception:       # noqa: BLE001
+                sib = {c}
+            if c == min(sib & cpus):
+                cores.add(c)
+        nodes[int(nd.name[4:])] = {"cpus": len(cpus), "cores": len(cores)}
+    ram = None
+    try:
+        for line in pathlib.Path("/proc/meminfo").read_text().splitlines():
+            if line.startswith("MemTotal:"):
+                ram = int(line.split()[1]) * 1024 / 1e9
+    except Exception:       # noqa: BLE001
+        pass
+    return {"source": "sysfs", "devices": devs[:gpus], "nodes": nodes, "host_ram_GB": ram, "cpu_quota": cpu_quota(), "hbm_GB": 288.0}
+
+
+def synthetic_topology(gpus, numa_nodes=2, cores_per_node=64, host_ram_GB=1536.0, hbm_GB=288.0, cpu_quota=None):
+    """An MI355X node as BASELINE config 5 assumes it when no such node is at hand: `gpus` cards spread evenly over `numa_nodes` sockets."""
+    return {"source": "assumed", "devices": [{"pci": None, "numa_node": r * numa_nodes // gpus} for r in range(gpus)],
+            "nodes": {k: {"cpus": 2 * cores_per_node, "cores": cores_per_node} for k in range(numa_nodes)}, "host_ram_GB": host_ram_GB, "cpu_quota": cpu_quota, "hbm_GB": hbm_GB}
+
+
+def plan_node(gpus, streams, steps, profile, topology, n=993384, N=1 << 20, q=1986769, m=512):
+    """What `bench.py --gpus N` will do on this node, rank by rank, from the planner the real run uses (cores_for_rank, plan_chain_pool) - no GPU call."""
+    ranks = []
+    n_streams = max(1, min(streams, steps))
+    for r in range(gpus):
+        node = topology["devices"][r]["numa_node"]
+        sharing = sum(1 for d in topology["devices"][:gpus] if d["numa_node"] == node)
+        quota = topology.get("cpu_quota")
+        per_rank = cores_for_rank(topology["nodes"][node]["cores"], sharing, None if quota is None else quota * sharing // max(1, gpus))
+        lanes = plan_chain_pool(per_rank, n_streams)
+        mem = memory_model(n, N, q, m, profile, n_streams)
+        ranks.append({"rank": r, "device": r, "pci": topology["devices"][r]["pci"], "numa_node": node, "ranks_on_node": sharing, "cores_for_rank": per_rank,
+                      "cpu_set": "the CPUs of NUMA node %d" % node, "chain_pool_lanes": lanes, "chain_threads": len(lanes), "chains_at_once": sum(lanes),
+                      "proving_streams": n_streams, "hbm_expected_GB": round(mem["hbm_GB"], 1), "pinned_host_expected_GB": round(mem["pinned_host_GB"], 2)})
+    pinned = sum(x["pinned_host_expected_GB"] for x in ranks)
+    fits = {"hbm_per_card": all(x["hbm_expected_GB"] <= topology["hbm_GB"] for x in ranks),
+            "pinned_host": topology.get("host_ram_GB") is None or pinned <= 0.5 * topology["host_ram_GB"],
+            "a_core_per_chain_thread": all(x["chain_threads"] + 2 <= x["cores_for_rank"] or x["cores_for_rank"] <= 2 for x in ranks)}
+    return {"plan_only": True, "gpus": gpus, "profile": profile, "steps": steps, "topology": {k: v for k, v in topology.items() if k != "devices"},
+            "ranks": ranks, "pinned_host_total_GB": round(pinned, 1), "fits": fits,
+            "note": "no GPU was touched; HBM and pinned memory from bench.memory_model (csrc/engine.hip's allocations restated), checked against the card in the real line "
+                    "(hbm_in_use beside hbm_model)"}
 
 
 def host_description():
@@ -512,7 +625,7 @@ def run_rank(args):
     if lanes_per_thread > 1:
         ctx.set_chain_lanes(lanes_per_thread)
     t0 = time.perf_counter()
-    a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=None if rank == 0 else rank)
+    a = workloads.merkle_full_tree(ctx, leaves=args.leaves, seed=(args.leaf_seed if rank == 0 else (args.leaf_seed or 0) + rank) if (rank or args.leaf_seed is not None) else None)
     inst = a.prover.instance()
     state = a.transcript.state
     t_asm = time.perf_counter() - t0
@@ -623,7 +736,7 @@ def run_rank(args):
         out = in_flight_throughput(bpg, ctx, res, inst, state, a.gens_capacity, device_index, max(args.in_flight, 2), max(2, args.in_flight_steps),
                                    workers=max(1, args.in_flight_workers), lanes=max(1, min(8, args.in_flight_lanes)))
         if rank == 0:
-            print(json.dumps({"in_flight": out}), flush=True)
+            print(json.dumps({"in_flight": out, "schedule": ctx.schedule(), "leaf_seed": args.leaf_seed}), flush=True)
         return
 
     # ---- warm-up (not steps: the first proof of a context sizes its device workspaces), then EXACTLY `steps` timed proofs
@@ -657,7 +770,9 @@ def run_rank(args):
     try:
         free_b, total_b = torch.cuda.mem_get_info(device_index)
         hbm_used = {"in_use_GB": (total_b - free_b) / 1e9, "total_GB": total_b / 1e9,
-                    "note": "device memory in use on this rank's GPU with all proving streams alive (generator tables and odd multiples once per device, workspaces per stream)"}
+                    "note": "device memory in use on this rank's GPU with all proving streams alive (generator tables and odd multiples once per device, workspaces per stream)",
+                    "model": memory_model(inst.n, a.gens_capacity, inst.q, inst.m, args.profile, n_streams, nnz=inst.nnz),
+                    "model_note": "bench.memory_model: csrc/engine.hip's allocations restated - what `--plan-only` quotes per rank"}
     except Exception:       # noqa: BLE001
         hbm_used = None
     del lanes[1:]                # the other legs use the first stream only
@@ -869,7 +984,15 @@ def run_rank(args):
                     "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
                             "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv)",
                     "valu": dom["valu"], "whole_proof": whole, "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
-        if n_streams > 1 and prof_isolated and ranked[0] in prof_isolated:
+        # the bucket sweep exists in two shapes (csrc/hip/k_msm.cuh): balanced chunks for a proof alone on the device, bucket-major (length-sorted blocks) while
+        # other proofs share it; `iso_name` = the kernel that does a kernel's job in the single-stream leg
+        def iso_name(n):
+            if not prof_isolated:
+                return None
+            if n in prof_isolated:
+                return n
+            return next((x for x in SWEEPS if n in SWEEPS and x in prof_isolated), None)
+        if n_streams > 1 and iso_name(ranked[0]):
             # with several proving streams a launch inside the timed steps shares the CUs with kernels of other proofs, and its duration says how
             # the GPU was shared, not how good the kernel is (14 streams: 2.4 - 3.1 ms per sweep from run to run, 0.97 ms alone).  The headline
             # figures of `roofline` are therefore the kernel ALONE on the GPU - HIP events in the single-stream leg of this same run, the
@@ -877,9 +1000,14 @@ def run_rank(args):
             shared = {k: roofline[k] for k in ("launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu", "other_kernels")}
             shared["note"] = ("the same kernel inside the timed steps, where %d proving streams share the GPU (HIP events on each stream, summed); "
                               "rocprofv3 --stats of the headline command: profiles/*_rocprof_kernel_stats.csv" % n_streams)
-            iso = kernel_roofline(ranked[0], prof_isolated)
+            iso = kernel_roofline(iso_name(ranked[0]), prof_isolated)
             for k in ("launches", "avg_launch_ms", "alg_bytes_per_launch", "achieved", "frac", "device_GBps", "valu"):
                 roofline[k] = iso[k]
+            if iso["kernel"] != roofline["kernel"]:
+                roofline["traffic"], roofline["traffic_useful_fetch"] = iso["traffic"], iso["traffic_useful_fetch"]      # the counter passes profile one stream alone
+                roofline["kernel_alone"] = iso["kernel"]
+                roofline["note"] += ("; the sweep of a proof alone on the device is %s (balanced chunks), of a proof that shares it %s (a lane per bucket, buckets "
+                                     "sorted by length inside a block: fewest instructions) - same sums, `timed_steps_shared` holds the second" % (iso["kernel"], roofline["kernel"]))
             roofline["other_kernels"] = [kernel_roofline(n, prof_isolated) for n in ranked[1:] if n in prof_isolated]
             roofline["measured"] = ("kernel alone on the GPU: HIP events on the engine's stream in the single-stream leg of this run (one proving stream, one "
                                     "chain thread; rocprofv3 --stats of that command: profiles/*_kernel_stats_single_stream.csv). `timed_steps_shared` = the "
@@ -891,7 +1019,7 @@ def run_rank(args):
     else:
         roofline = {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": 8000.0, "unit": "GB/s", "frac": 0.0, "traffic": None, "whole_proof": whole,
                     "note": "no fold / bucket-sweep launch in the timed steps (table-driven schedule at this size)"}
-    if ranked and roofline.get("kernel") == "k_bucket_chunks":
+    if ranked and roofline.get("kernel") in SWEEPS:
         # both term counts of the bucket sweep: what the launches process - the rounds of a fold group run on the group-start tables
         # with expanded scalars, so rounds 2 and 3 of a group visit as many terms as round 1 - and what the survey's round sizes add up to
         # (A_I, A_O, S: 5n terms; L_k, R_k of round k: 2 N_k terms for the rounds above the table-driven tail)
@@ -899,8 +1027,9 @@ def run_rank(args):
         survey_terms = 5 * inst.n
         while (tt_lg == 0 or (N >> k) > (1 << tt_lg)) and (N >> k) > 1:
             survey_terms += 2 * (N >> k); k += 1
-        iso = n_streams > 1 and prof_isolated and "k_bucket_chunks" in prof_isolated
-        sweeps = (prof_isolated if iso else prof)["k_bucket_chunks"]
+        iso = n_streams > 1 and prof_isolated and any(x in prof_isolated for x in SWEEPS)
+        src_prof = prof_isolated if iso else prof
+        sweeps = src_prof[next(x for x in SWEEPS if x in src_prof)]
         proofs_seen = single["steps"] if iso else args.steps
         processed = sweeps["alg_bytes"] / 64.0
         secs = sweeps["total_ms"] * 1e-3
@@ -1034,6 +1163,10 @@ def run_rank(args):
 
 def main():
     args = parse_args()
+    if args.plan_only:
+        topo = discover_topology(args.gpus) or synthetic_topology(args.gpus)
+        print(json.dumps(plan_node(args.gpus, args.streams, args.steps if args.steps > 3 else 20, args.profile, topo)), flush=True)
+        return
     if args.headline_only:
         args.no_cpu_baseline, args.in_flight = True, 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -24,8 +24,8 @@ import sys
 from . import (BoundsCheck, BulletproofGens, ConstraintBuffer, Context, Equality, or_conjunction, Inequality, LessThan, MerkleTree256, MimcHash256, Prover,
                SetMembership, Transcript, Verifier, be_to_scalar, be_to_scalars, commit, commit_single, mimc_hash, scalar_to_be, L)
 
-MAX_OR_NESTING = 64      # OR blocks may nest (reference src/bin/prover.rs:219-234); the file is untrusted input, so the recursion is bounded (csrc/cli_main.cpp: same bound)
 _VAR = re.compile(r"^\s*([A-Za-z][0-9]+(?:-[0-9]+){0,2})\s*=\s*0[xX]([0-9a-fA-F]+)\s*$")
+MAX_OR_NESTING = 64      # OR blocks may nest (reference src/bin/prover.rs:219-234); the file is untrusted input, so the recursion is bounded (csrc/cli_main.cpp: same bound)
 
 
 def _read_vars(path):

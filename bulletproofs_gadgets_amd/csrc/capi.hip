@@ -209,7 +209,7 @@ bpg_status bpg_pedersen_commit(bpg_ctx *ctx, uint64_t k, const uint8_t *v, const
     return guard([&] { REQUIRE(ctx && (k == 0 || (v && blind && out))); ctx->engine->pedersen_commit(k, v, blind, out); });
 }
 bpg_status bpg_test_fe_ops(bpg_ctx *ctx, int32_t op, uint64_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
-    return guard([&] { REQUIRE(ctx && op >= 0 && op <= 5 && (n == 0 || (a && b && out))); ctx->engine->test_fe_ops(op, n, a, b, out); });
+    return guard([&] { REQUIRE(ctx && op >= 0 && op <= 6 && (n == 0 || (a && b && out))); ctx->engine->test_fe_ops(op, n, a, b, out); });
 }
 bpg_status bpg_msm_gens(bpg_ctx *ctx, uint64_t first, uint64_t count, const uint8_t *s, const uint8_t *t, uint8_t out[32]) {
     return guard([&] { REQUIRE(ctx && out && (count == 0 || (s && t))); ctx->engine->msm_gens(first, count, s, t, out); });

@@ -196,14 +196,20 @@ struct DeviceCircuit {
     bool has_witness = false;
     uint64_t const_begin = 0;      // first entry of the constant-terms column (the last one)
     DevBuf aL, aR, aO, col_ptr, ent_row, ent_coef, coef;
+    // equal-scalar merging of A_I and A_O (hip/k_merge.cuh), built at the first prove() of this witness: terms of <a_L, G> + <a_R, H> (of <a_O, G>) that carry
+    // the same scalar -> one term on the sum of their generators (pts, affine Niels) with that scalar (sc); skipA / skipB mark the terms that were merged away
+    // (one bit per multiplier: a_L and a_R for A_I, a_O for A_O)
+    struct MergeSet { uint32_t groups = 0, skipped = 0; DevBuf skipA, skipB, sc, pts; };
+    bool merge_tried = false;
+    MergeSet mI, mO;
 };
 
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_blind_poison) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
-    X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr)
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_sorted) X(k_bucket_heavy_parts) X(k_bucket_heavy_join) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr) X(k_merge_insert) X(k_merge_plan) X(k_merge_groups) X(k_merge_members) X(k_merge_sum)
 enum KernelId {
 #define X(n) KID_##n,
     BPG_KERNELS(X)
@@ -227,7 +233,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks)); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks || id == KID_k_bucket_sorted)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -242,8 +248,17 @@ struct Engine::Impl {
     std::shared_ptr<SharedTables> shared;       // the generation of generator tables this context works on
     DevBuf gens;                                // view of shared->gens (not owned)
     DevBuf bases, scratch_ext, comp, small_in, small_sc;
+    // One arena for the large per-stream buffers whose lifetimes never overlap in stream order (round 5: 20 proving streams held 2.9 GB each):
+    //   an MSM:        [digits | entries1] (dead once k_msm_sort2 has run) overlaid by the sweep's partial sums (slots); entries behind them
+    //   poly phase:    flattened weights, powers of z and y (between the S sums and the first round of the inner-product argument)
+    //   IPA tail:      the window tables of the folded generators (0.54 GB; no MSM runs once the tail has started)
+    // Everything is queued on ONE stream, so a later phase's kernels start after the earlier phase's have finished.  Growing the arena frees it first
+    // (hipFree synchronises the device), exactly as growing any DevBuf does.
+    DevBuf arena;
+    uint8_t *arena_at(size_t off) const { return arena.as<uint8_t>() + off; }
+    static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, entries, buckets, partial, msm_result, slots, open_keys, medium, wsums, tile_hist, heavy, plain, digits, entries1, starts1;   // tile_hist, plain: workspace of upload()
+    DevBuf counts, starts, cursor, blocksum, buckets, partial, msm_result, open_keys, medium, wsums, tile_hist, heavy, plain, starts1;   // tile_hist, plain: workspace of upload(); digits, the entry lists and the sweep's partial sums live in the arena
     uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 4 per CU of the device the context is created on (BPG_SWEEP_RESIDENT overrides)
     uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps)
     uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (digits are 16-bit)
@@ -253,8 +268,18 @@ struct Engine::Impl {
     uint32_t profile = 1;           // 1 one-shot, 2 serving (what bpg_config / BPG_PROFILE settled on)
     bool shared_now = false;        // sampled ONCE per prove()/verify(): does this call take the shared-device variants (shared_variants())
     uint32_t msm_cmin = 2;          // BPG_MSM_CMIN: narrowest window (tests: wide windows on small sums)
+    uint32_t sweep_mode = 0;        // BPG_SWEEP: 0 balanced chunks (default: the bucket-major sweep measured slower in the mix), 1 bucket-major (length-sorted blocks) while the device is shared, 2 bucket-major always
+    uint32_t sweep_per = 8;         // BPG_SWEEP_PER: buckets per thread of a bucket-major block (2, 4, 8 or 16: 512 .. 4,096 buckets per block)
+    uint32_t merge_equal = 1;       // BPG_MERGE: 0 A_I and A_O term by term; 1 equal scalars grouped once per uploaded witness (at its first proof); 2 grouped afresh in EVERY
+                                    // proof (what a host that proves each witness once pays: the measurement behind bench.py's `merge_per_proof`); same bytes
+    uint32_t merged_last = 0, merged_skipped_last = 0;   // witness of the last prove(): groups of equal scalars in A_I and A_O, and the terms they replace (0: none, or the table-driven path)
+    uint32_t msm_skipped_terms = 0; // terms of the next msm() call whose skip bit is set (they make no entries): the window width and the entry bound are sized for the rest
+    uint32_t msm_alg_discount = 0;  // terms of the next msm() call that are not terms of the sum it computes (merged-point terms stand in for terms that were skipped): roofline bookkeeping only
+    void merge_witness(DeviceCircuit *c, const ge_niels *Gtab, const ge_niels *Htab);
+    void merge_build(DeviceCircuit::MergeSet &M, const scm *A, const ge_niels *PA, uint32_t nA, const scm *B, const ge_niels *PB, uint32_t nB);
+    double merge_ms_last = 0;       // wall time of the last merge_witness() that did something (once per uploaded witness)
     // prove buffers
-    DevBuf sLR, wAll, ypow, yinvpow, zpow, lv, rv, red_partial, red_out, raw_rng, extras;
+    DevBuf sLR, yinvpow, lv, rv, red_partial, red_out, raw_rng, extras;      // (y^i, z^j and the flattened weights: in the arena)
     DevBuf stale_flag;              // one word, zero unless k_sc_from_wide met a poisoned (never uploaded) draw: checked before a proof leaves prove()
     DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
@@ -262,15 +287,23 @@ struct Engine::Impl {
     // tt_table holds the tables of the ORIGINAL generators G[0..M0), H[0..M0) when tt_orig_M0 != 0: they survive across proofs (a circuit
     // with N <= 2^tt_orig_lg freezes its generators at round 0) and also serve A_I, A_O, S (k_tt_commit3)
     uint32_t tt_orig_M0 = 0; const void *tt_orig_gens = nullptr;
+    ge_pniels *tt_table_p = nullptr;            // the window tables in use: tt_table (original generators) or the arena (folded ones), set by tt_build
     void tt_build(const ge_niels *G, const ge_niels *H, const ge_niels *B, uint32_t M0, bool original) {
         const uint32_t npts = 2 * M0 + 1;
-        if (original && tt_orig_M0 == M0 && tt_orig_gens == gens.p) return;
+        if (original && tt_orig_M0 == M0 && tt_orig_gens == gens.p) { tt_table_p = tt_table.as<ge_pniels>(); return; }
         tt_orig_M0 = 0;
-        tt_bases.ensure((size_t)npts * TT_WINDOWS * sizeof(ge_ext));
-        tt_table.ensure((size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels));
+        const size_t bb = al256((size_t)npts * TT_WINDOWS * sizeof(ge_ext)), tb = (size_t)npts * TT_WINDOWS * TT_MULTS * sizeof(ge_pniels);
+        ge_ext *basesp;
+        if (original) {     // tables of the ORIGINAL generators outlive the proof (and serve A_I, A_O, S of the next one): buffers of their own
+            tt_bases.ensure(bb); tt_table.ensure(tb);
+            basesp = tt_bases.as<ge_ext>(); tt_table_p = tt_table.as<ge_pniels>();
+        } else {            // tables of FOLDED generators live for the tail of one proof: in the arena, where the MSM workspace of the rounds before was
+            arena.ensure(bb + tb);
+            basesp = reinterpret_cast<ge_ext *>(arena_at(0)); tt_table_p = reinterpret_cast<ge_pniels *>(arena_at(bb));
+        }
         tt_partial.ensure((size_t)3 * cdiv((uint64_t)M0 * 16, 256) * sizeof(ge_ext));
-        BPG_LAUNCH((*this), k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), G, H, B, tt_bases.as<ge_ext>(), M0);
-        BPG_LAUNCH((*this), k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), tt_bases.as<ge_ext>(), tt_table.as<ge_pniels>(), npts * TT_WINDOWS);
+        BPG_LAUNCH((*this), k_tt_bases, dim3(cdiv(npts, 64)), dim3(256), G, H, B, basesp, M0);
+        BPG_LAUNCH((*this), k_tt_multiples, dim3(cdiv((uint64_t)npts * TT_WINDOWS, 256)), dim3(256), basesp, tt_table_p, npts * TT_WINDOWS);
         if (original) { tt_orig_M0 = M0; tt_orig_gens = gens.p; }
     }
     // 8-bit window tables of the original generators (kernels.cuh k_tt_round8): shared per device like the fold tables, built on first use
@@ -522,6 +555,9 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
     if (env_present("BPG_MSM_CMAX")) K->msm_cmax = K->msm_cmax_shared = (uint32_t)env_int_strict("BPG_MSM_CMAX", 4, 16);
     env_set("BPG_MSM_CMIN", 2, 16, K->msm_cmin);
+    env_set("BPG_SWEEP", 0, 2, K->sweep_mode);
+    if (env_present("BPG_SWEEP_PER")) { const long v = env_int_strict("BPG_SWEEP_PER", 2, 16); if (v & (v - 1)) throw std::invalid_argument("BPG_SWEEP_PER: 2, 4, 8 or 16"); K->sweep_per = (uint32_t)v; }
+    env_set("BPG_MERGE", 0, 2, K->merge_equal);
     bool resident_set = false;
     if (env_present("BPG_SWEEP_RESIDENT")) { K->sweep_blocks_resident = (uint32_t)env_int_strict("BPG_SWEEP_RESIDENT", 64, 65536); resident_set = true; }
     if (env_present("BPG_RSEG")) {
@@ -589,10 +625,10 @@ Engine::~Engine() {
     (void)hipStreamSynchronize(impl_->st);
     for (auto &sd : impl_->slab_dev) if (sd->copy_st) (void)hipStreamSynchronize(sd->copy_st);
     DevBuf *bufs[] = {&impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
-                      &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->entries, &impl_->buckets, &impl_->partial, &impl_->msm_result,
-                      &impl_->sLR, &impl_->wAll, &impl_->ypow, &impl_->yinvpow, &impl_->zpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->slots, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
-                      &impl_->stale_flag, &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->digits, &impl_->entries1, &impl_->starts1};
+                      &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->arena, &impl_->buckets, &impl_->partial, &impl_->msm_result,
+                      &impl_->sLR, &impl_->yinvpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
+                      &impl_->stale_flag, &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
     impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
@@ -613,13 +649,13 @@ std::string Engine::profile_report() {
     impl_->prof_collect();
     // the effective schedule of this context first (what the knobs, the profile and the table budget settled on): bench.py derives its term
     // counts from THIS, not from its own reading of the environment
-    char sch[640];
+    char sch[896];
     std::snprintf(sch, sizeof sch, "{\"_schedule\": {\"profile\": %u, \"tt_lg\": %u, \"tt_orig_lg\": %u, \"fold_group\": %u, \"fold_wnaf\": %u, \"fold_parts\": %u, "
                   "\"eff_wnaf\": %u, \"eff_parts\": %u, \"fold_adapt\": %u, \"fold_split_max\": %u, \"fold_quad\": %u, \"msm_cmax\": %u, \"msm_cmax_shared\": %u, \"msm_cmin\": %u, "
-                  "\"rseg\": %u, \"lgch\": %u, \"sweep_blocks_resident\": %u, \"shared_variants_last\": %u, \"table_budget\": %llu, \"table_bytes\": %llu}",
+                  "\"rseg\": %u, \"lgch\": %u, \"sweep_blocks_resident\": %u, \"shared_variants_last\": %u, \"merge_equal\": %u, \"merged_last\": %u, \"merged_skipped_last\": %u, \"merge_ms_last\": %.3f, \"sweep_mode\": %u, \"sweep_per\": %u, \"table_budget\": %llu, \"table_bytes\": %llu}",
                   impl_->profile, impl_->tt_lg, impl_->tt_orig_lg, impl_->fold_group, impl_->fold_wnaf, impl_->fold_parts, impl_->eff_wnaf, impl_->eff_parts,
                   impl_->fold_adapt, impl_->fold_split_max, (unsigned)impl_->fold_quad, impl_->msm_cmax, impl_->msm_cmax_shared, impl_->msm_cmin, impl_->rseg, impl_->lgch,
-                  impl_->sweep_blocks_resident, (unsigned)impl_->shared_now, (unsigned long long)impl_->table_budget, (unsigned long long)table_bytes_held(device_));
+                  impl_->sweep_blocks_resident, (unsigned)impl_->shared_now, (unsigned)impl_->merge_equal, impl_->merged_last, impl_->merged_skipped_last, impl_->merge_ms_last, impl_->sweep_mode, impl_->sweep_per, (unsigned long long)impl_->table_budget, (unsigned long long)table_bytes_held(device_));
     std::string out = sch;
     bool first = false;
     for (int i = 0; i < KID_COUNT; i++) {
@@ -727,6 +763,7 @@ void Engine::gens_ensure(uint64_t capacity) {
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(I.st));
     publish(fresh);
+    I.raw_rng.release(); I.scratch_ext.release(); I.h_raw.release();      // one-off derivation buffers (0.4 GB of device memory at 2^20); the prove path sizes its own
     if (cache_ok) I.gens_store_cached(cache_file, cap);
 }
 
@@ -736,7 +773,7 @@ bool Engine::Impl::gens_load_cached(const std::string &path, uint64_t cap, DevBu
     if (!f) { if (fd >= 0) ::close(fd); return false; }
     const size_t bytes = (size_t)2 * cap * sizeof(ge_niels);
     GensCacheHeader hd;
-    bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, kGensMagic, 8) == 0 && hd.version == 1 && hd.capacity == cap && hd.bytes == bytes;
+    bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, kGensMagic, 8) == 0 && hd.version == 2 && hd.capacity == cap && hd.bytes == bytes;
     PinBuf host;
     if (ok) { host.ensure(bytes); ok = std::fread(host.p, 1, bytes, f) == bytes && std::fgetc(f) == EOF; }
     std::fclose(f);
@@ -776,7 +813,7 @@ void Engine::Impl::gens_store_cached(const std::string &path, uint64_t cap) {
     std::vector<uint8_t> host(bytes);
     HIPCHK(hipMemcpyAsync(host.data(), gens.p, bytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    GensCacheHeader hd; std::memcpy(hd.magic, kGensMagic, 8); hd.version = 1; hd.capacity = cap; hd.bytes = bytes; hd.checksum = gens_checksum(host.data(), bytes);
+    GensCacheHeader hd; std::memcpy(hd.magic, kGensMagic, 8); hd.version = 2; hd.capacity = cap; hd.bytes = bytes; hd.checksum = gens_checksum(host.data(), bytes);
     std::string tmp = path + ".tmp.XXXXXX";
     const int fd = ::mkstemp(&tmp[0]);                          // O_CREAT | O_EXCL, mode 0600, never through a symbolic link
     FILE *f = fd >= 0 ? ::fdopen(fd, "wb") : nullptr;
@@ -836,16 +873,18 @@ void Engine::pedersen_commit(size_t k, const uint8_t *v, const uint8_t *blind, u
 Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     const uint32_t total = S.start[S.nseg];
     if (nmsm < 1 || nmsm > 4) throw std::logic_error("msm: 1..4 results per call");
-    uint32_t per = total / nmsm; if (per < 1) per = 1;
+    const uint32_t live = total - std::min(total, msm_skipped_terms);       // terms that can make entries (the others were merged away: MsmSegs::skip)
+    msm_skipped_terms = 0;
+    uint32_t per = live / nmsm; if (per < 1) per = 1;
     const int cap = (int)(shared_now ? msm_cmax_shared : msm_cmax);
     int cc = (int)ceil_log2(per) - 4; if (cc < (int)msm_cmin) cc = (int)msm_cmin; if (cc > cap) cc = cap;
     uint32_t maxseg = 1; for (uint32_t k = 0; k < S.nseg; k++) maxseg = std::max(maxseg, S.len[k]);
-    // two-level sort: entry = sign | fb fine bits | 3 segment bits | index in segment -> 28 - fb index bits; at most 512 coarse bins
+    // two-level sort: entry = sign | fb fine bits | 4 segment bits | index in segment -> 27 - fb index bits; at most 512 coarse bins
     uint32_t fb = 0;
     {
         const uint32_t lgseg = ceil_log2(maxseg);
         if (lgseg > 27) throw std::invalid_argument("msm: segment too long");
-        const uint32_t fbmax = std::min<uint32_t>(7, 28 - lgseg);
+        const uint32_t fbmax = std::min<uint32_t>(7, 27 - lgseg);
         if (cc - 1 > (int)fbmax + 9) cc = (int)fbmax + 10;
         fb = std::min<uint32_t>(fbmax, (uint32_t)cc - 1);
     }
@@ -876,13 +915,12 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     }
     const uint32_t ntiles = P.tile_start[nmsm];
     starts.ensure((size_t)(nkeys + 1) * 4);
-    entries.ensure((size_t)(total ? total : 1) * W * 4);
     buckets.ensure((size_t)nkeys * sizeof(ge_ext));
     partial.ensure((size_t)2 * nmsm * W * nsegpw * sizeof(ge_ext));       // acc and run of every segment
     // balanced sweep: CH sorted entries per thread.  About 32, adjusted so that the launch's blocks fill the device a whole number of times: the
     // sweep keeps sweep_blocks_resident blocks of 256 threads on the CUs at once (4 waves per SIMD at its register count), and 4.25 rounds of
     // blocks cost what 5 do.  BPG_LGCH pins a power of two instead (diagnostics).
-    const uint64_t Mub = (uint64_t)total * W;                   // upper bound of the entry count (zero digits are skipped)
+    const uint64_t Mub = (uint64_t)live * W;                    // upper bound of the entry count (zero digits are skipped)
     uint32_t CH = 32;
     if (lgch) CH = 1u << lgch;
     else if (shared_now && Mub >= (uint64_t)sweep_blocks_resident * 256 * 64) CH = 64;      // other proofs fill the device and this sweep is long: longer chunks, half the boundary pieces to combine (18.7 against 19.2 ms per proof sustained)
@@ -893,36 +931,59 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         CH = (uint32_t)std::max<uint64_t>(4, (Mub + slots * rounds - 1) / (slots * rounds));
     }
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, CH);
-    heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4); medium.ensure(((size_t)nchunks / 2 + 2) * 4);      // a bucket on the medium list crosses at least two boundaries
+    // arena layout of this call: [digits | entries1] overlaid by the sweep's partial sums, then entries
+    const bool sorted_ = sweep_mode == 2 || (sweep_mode == 1 && shared_now);
+    const size_t b_digits = al256((size_t)(total ? total : 1) * W * 2), b_e1 = al256((size_t)(live ? live : 1) * W * 4), b_entries = b_e1;
+    const size_t b_slots = al256(sorted_ ? ((size_t)(Mub / BSORT_PART) + (size_t)(Mub / (BSORT_LCAP + 1)) + 1) * sizeof(ge_ext) : (size_t)nchunks * 2 * sizeof(ge_ext));
+    const size_t b_front = std::max(b_digits + b_e1, b_slots);
+    arena.ensure(b_front + b_entries);
+    uint16_t *digits_p = reinterpret_cast<uint16_t *>(arena_at(0));
+    uint32_t *entries1_p = reinterpret_cast<uint32_t *>(arena_at(b_digits)), *entries_p = reinterpret_cast<uint32_t *>(arena_at(b_front));
+    ge_ext *slots_p = reinterpret_cast<ge_ext *>(arena_at(0));
+    // bucket-major sweep (k_bucket_sorted): a lane per bucket, buckets sorted by length inside a block; buckets of 256 entries and more in parts
+    const bool sorted = sorted_;
+    const uint32_t maxheavy = (uint32_t)(Mub / (BSORT_LCAP + 1)) + 1, maxparts = (uint32_t)(Mub / BSORT_PART) + maxheavy;
+    if (sorted) { heavy.ensure(((size_t)2 * maxheavy + 4) * 4); medium.ensure(((size_t)maxparts + 1) * sizeof(uint2)); }
+    else { heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4); medium.ensure(((size_t)nchunks / 2 + 2) * 4); }      // a bucket on the medium list crosses at least two boundaries
     {
         // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
         const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
         if (nflat64 >= (1ull << 31)) throw std::invalid_argument("msm: too many tiles");
         const uint32_t nflat = (uint32_t)nflat64, nblk1 = cdiv(nflat, SCAN_CHUNK), K = nmsm * W * P.CB;
-        digits.ensure((size_t)(total ? total : 1) * W * 2);
-        entries1.ensure((size_t)(total ? total : 1) * W * 4);
         counts.ensure((size_t)(nflat + 1) * 4); starts1.ensure((size_t)(nflat + 1) * 4); cursor.ensure((size_t)(nflat + 1) * 4);
         blocksum.ensure((size_t)(nblk1 + 1) * 4);
-        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits.as<uint16_t>(), heavy.as<uint32_t>(), medium.as<uint32_t>());
+        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits_p, heavy.as<uint32_t>(),
+                   sorted ? heavy.as<uint32_t>() + 1 : medium.as<uint32_t>());                     // (zeroes the two list counters of the sweep that follows)
         HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
-        if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits.as<uint16_t>(), total, counts.as<uint32_t>());
+        if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits_p, total, counts.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk1);
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
-        if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits.as<uint16_t>(), total, starts1.as<uint32_t>(), entries1.as<uint32_t>());
-        BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1.as<uint32_t>(), starts.as<uint32_t>(), entries.as<uint32_t>());
+        if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits_p, total, starts1.as<uint32_t>(), entries1_p);
+        BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1_p, starts.as<uint32_t>(), entries_p);
     }
-    {
-        slots.ensure((size_t)nchunks * 2 * sizeof(ge_ext)); open_keys.ensure((size_t)nchunks * 4);
-        ge_ext *slotA = slots.as<ge_ext>(), *slotB = slotA + nchunks;
+    if (sorted) {
+        uint2 *partlist = medium.as<uint2>();
+        const uint32_t KB = 256u * sweep_per, nblk = cdiv(nkeys, KB);
+#define BPG_SORTED(PER) BPG_LAUNCH_ID((*this), KID_k_bucket_sorted, k_bucket_sorted<PER>, dim3(nblk), dim3(256), S, starts.as<uint32_t>(), entries_p, buckets.as<ge_ext>(), nkeys, heavy.as<uint32_t>(), partlist)
+        if (sweep_per == 2) BPG_SORTED(2); else if (sweep_per == 4) BPG_SORTED(4); else if (sweep_per == 16) BPG_SORTED(16); else BPG_SORTED(8);
+#undef BPG_SORTED
+        prof_note(KID_k_bucket_sorted, 64.0 * (double)(total - std::min(total, msm_alg_discount)), 100.0 * (double)Mub, 7.0 * (double)Mub);
+        msm_alg_discount = 0;
+        BPG_LAUNCH((*this), k_bucket_heavy_parts, dim3(cdiv(maxparts, 256)), dim3(256), S, starts.as<uint32_t>(), entries_p, heavy.as<uint32_t>(), partlist, slots_p);
+        BPG_LAUNCH((*this), k_bucket_heavy_join, dim3(64), dim3(256), starts.as<uint32_t>(), heavy.as<uint32_t>(), slots_p, buckets.as<ge_ext>());
+    } else {
+        open_keys.ensure((size_t)nchunks * 4);
+        ge_ext *slotA = slots_p, *slotB = slotA + nchunks;
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
-        BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries.as<uint32_t>(),
+        BPG_LAUNCH((*this), k_bucket_chunks, dim3(cdiv(nchunks, 256)), dim3(256), S, starts.as<uint32_t>(), entries_p,
                    buckets.as<ge_ext>(), slotA, slotB, open_keys.as<uint32_t>(), nkeys, CH);
         // roofline bookkeeping.  Algorithmic bytes: the information content of the MSM this launch sweeps, one scalar + one
         // point = 64 B per TERM, counted once however many windows the term is cut into.  Device bytes: every (term, window) entry is a
         // 4-byte index and a 96-byte affine Niels point.  Work: one mixed addition (7 field multiplications) per entry; Mub counts zero
         // digits too (probability 2^-c each for full-width scalars).
-        prof_note(KID_k_bucket_chunks, 64.0 * (double)total, 100.0 * (double)Mub, 7.0 * (double)Mub);
+        prof_note(KID_k_bucket_chunks, 64.0 * (double)(total - std::min(total, msm_alg_discount)), 100.0 * (double)Mub, 7.0 * (double)Mub);
+        msm_alg_discount = 0;
         // joining the pieces of buckets that cross chunk boundaries: one thread per boundary where chunks are at least as long as the average bucket
         // (the shared-device shape: 64-entry chunks, ~32 entries per bucket), one thread per bucket where buckets are longer (a proof alone)
         if ((uint64_t)CH * nkeys >= Mub)
@@ -947,11 +1008,11 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
 }
 
 namespace {
-void seg_push(MsmSegs &S, const scm *sc, const ge_niels *pts, uint32_t len, uint32_t msm, uint32_t lgblk = 31) {
+void seg_push(MsmSegs &S, const scm *sc, const ge_niels *pts, uint32_t len, uint32_t msm, uint32_t lgblk = 31, const uint32_t *skip = nullptr) {
     if (!len) return;
     if (S.nseg >= BPG_MAX_SEGS) throw std::logic_error("too many MSM segments");
     uint32_t k = S.nseg++;
-    S.sc[k] = sc; S.pts[k] = pts; S.len[k] = len; S.msm[k] = msm; S.lgblk[k] = lgblk;
+    S.sc[k] = sc; S.pts[k] = pts; S.len[k] = len; S.msm[k] = msm; S.lgblk[k] = lgblk; S.skip[k] = skip;
     S.start[k + 1] = S.start[k] + len;
 }
 MsmSegs seg_new() { MsmSegs S; std::memset(&S, 0, sizeof S); return S; }
@@ -1006,13 +1067,13 @@ DeviceCircuit *Engine::upload(const FlatView &c) {
         d->coef.ensure((ncoef ? ncoef : 1) * sizeof(scm));
         {
             // the CSR arrays travel as they are; workspace: the MSM sort buffers (no MSM runs on this context during an upload)
-            I.entries.ensure((nnz ? nnz : 1) * 8);                              // term_var | term_coef
+            I.arena.ensure((nnz ? nnz : 1) * 8);                                // term_var | term_coef
             I.plain.ensure((q + 2) * 8 + 64);                                   // row_ptr
             I.counts.ensure((std::max<uint64_t>(nvar, q) + 2) * 4); I.starts.ensure((std::max<uint64_t>(nvar, q) + 2) * 4);
             I.cursor.ensure((std::max<uint64_t>(nvar, q) + 2) * 4); I.heavy.ensure((q + 2) * 4); I.tile_hist.ensure((q + 2) * 4 + 64);
             const uint32_t nb1 = cdiv(nvar ? nvar : 1, SCAN_CHUNK), nb2 = cdiv(q ? q : 1, SCAN_CHUNK);
             I.blocksum.ensure((size_t)(std::max(nb1, nb2) + 2) * 4);
-            uint32_t *tv = I.entries.as<uint32_t>(), *tc = tv + (nnz ? nnz : 1);
+            uint32_t *tv = I.arena.as<uint32_t>(), *tc = tv + (nnz ? nnz : 1);
             uint64_t *rp = I.plain.as<uint64_t>();
             uint32_t *rowconst = I.heavy.as<uint32_t>(), *rowconst_start = I.tile_hist.as<uint32_t>();
             if (nnz) {
@@ -1061,9 +1122,65 @@ DeviceCircuit *Engine::upload(const FlatView &c) {
 void Engine::free_circuit(DeviceCircuit *c) {
     if (!c) return;
     (void)hipSetDevice(device_);
-    DevBuf *b[] = {&c->aL, &c->aR, &c->aO, &c->col_ptr, &c->ent_row, &c->ent_coef, &c->coef};
+    DevBuf *b[] = {&c->aL, &c->aR, &c->aO, &c->col_ptr, &c->ent_row, &c->ent_coef, &c->coef, &c->mI.skipA, &c->mI.skipB, &c->mI.sc, &c->mI.pts, &c->mO.skipA, &c->mO.skipB, &c->mO.sc, &c->mO.pts};
     for (DevBuf *x : b) x->release();
     delete c;
+}
+
+// ------------------------------------------------------------------------------------------------ equal-scalar merging of A_I, A_O (hip/k_merge.cuh)
+// Built once per uploaded witness, at its first prove() on the bucket-method path (the generator tables must exist; upload() may precede them).  Cost at
+// n = 993,384: a hash-table pass over the scalars, two scans over the table, one point addition per merged-away term and a batched normalisation.
+void Engine::Impl::merge_build(DeviceCircuit::MergeSet &M, const scm *A, const ge_niels *PA, uint32_t nA, const scm *B, const ge_niels *PB, uint32_t nB) {
+    const uint32_t nterms = nA + nB;
+    if (nterms < 2) return;
+    MergeTerms T; T.A = A; T.B = B; T.PA = PA; T.PB = PB; T.nA = nA; T.nterms = nterms;
+    const uint32_t lgslots = ceil_log2((uint64_t)2 * nterms), slots = 1u << lgslots;        // load <= 1/2
+    const uint32_t nblk = cdiv(slots, SCAN_CHUNK);
+    // workspace out of the arena (no MSM of this context is in flight: prove() calls this before its first launch)
+    const size_t words = (size_t)7 * slots + 2 * (size_t)nterms + (size_t)nterms / 2 + 8;
+    arena.ensure(words * 4); blocksum.ensure((size_t)(nblk + 1) * 4);
+    uint32_t *rep = arena.as<uint32_t>(), *count = rep + slots, *msize = count + slots, *gcount = msize + slots, *moff = gcount + slots, *goff = moff + slots + 1,
+             *fill = goff + slots + 1, *slot_of = fill + slots, *members = slot_of + nterms, *gslot = members + nterms;
+    const uint32_t wA = (nA + 31) / 32, wB = (nB + 31) / 32;
+    M.skipA.ensure((size_t)std::max(wA, 1u) * 4); M.skipB.ensure((size_t)std::max(wB, 1u) * 4);
+    HIPCHK(hipMemsetAsync(rep, 0xff, (size_t)slots * 4, st));
+    HIPCHK(hipMemsetAsync(count, 0, (size_t)slots * 4, st));
+    HIPCHK(hipMemsetAsync(M.skipA.p, 0, (size_t)std::max(wA, 1u) * 4, st)); HIPCHK(hipMemsetAsync(M.skipB.p, 0, (size_t)std::max(wB, 1u) * 4, st));
+    BPG_LAUNCH((*this), k_merge_insert, dim3(cdiv(nterms, 256)), dim3(256), T, rep, count, slot_of, lgslots);
+    BPG_LAUNCH((*this), k_merge_plan, dim3(cdiv(slots, 256)), dim3(256), count, msize, gcount, slots);
+    auto scan = [&](uint32_t *in, uint32_t *out) {        // exclusive scan of in[0..slots) -> out[0..slots], out[slots] = total; `fill` is the scan's scratch cursor
+        BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk), dim3(256), in, slots, blocksum.as<uint32_t>());
+        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk);
+        BPG_LAUNCH((*this), k_scan_apply, dim3(nblk), dim3(256), in, slots, blocksum.as<uint32_t>(), out, fill);
+    };
+    scan(msize, moff); scan(gcount, goff);
+    HIPCHK(hipGetLastError());
+    uint32_t tot[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&tot[0], moff + slots, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&tot[1], goff + slots, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const uint32_t skipped = tot[0], groups = tot[1];
+    if (groups == 0 || skipped > nterms || groups > nterms / 2) return;        // (a group has at least two of the terms)
+    HIPCHK(hipMemsetAsync(fill, 0, (size_t)slots * 4, st));
+    M.sc.ensure((size_t)groups * sizeof(scm)); M.pts.ensure((size_t)groups * sizeof(ge_niels));
+    scratch_ext.ensure((size_t)groups * sizeof(ge_ext));
+    BPG_LAUNCH((*this), k_merge_groups, dim3(cdiv(slots, 256)), dim3(256), count, goff, gslot, slots);
+    BPG_LAUNCH((*this), k_merge_members, dim3(cdiv(nterms, 256)), dim3(256), T, slot_of, count, moff, fill, members, M.skipA.as<uint32_t>(), M.skipB.as<uint32_t>());
+    BPG_LAUNCH((*this), k_merge_sum, dim3(cdiv(groups, 64)), dim3(64), T, count, moff, goff, gslot, members, groups, scratch_ext.as<ge_ext>(), M.sc.as<scm>());
+    BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(groups, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), M.pts.as<ge_niels>(), groups);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    M.groups = groups; M.skipped = skipped;
+}
+void Engine::Impl::merge_witness(DeviceCircuit *c, const ge_niels *Gtab, const ge_niels *Htab) {
+    if (c->merge_tried) return;
+    c->merge_tried = true;
+    const uint32_t n = (uint32_t)c->n;
+    if (!merge_equal || n < 2) return;
+    const double t0 = now_ms();
+    merge_build(c->mI, c->aL.as<scm>(), Gtab, n, c->aR.as<scm>(), Htab, n);
+    merge_build(c->mO, c->aO.as<scm>(), Gtab, n, nullptr, nullptr, 0);
+    merge_ms_last = now_ms() - t0;
 }
 
 // ------------------------------------------------------------------------------------------------ inner-product argument
@@ -1083,7 +1200,6 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
         const uint64_t half = N / 2;
         I.ipa_s.ensure(4 * half * sizeof(scm));
         I.ipa_tabA.ensure(2 * half * sizeof(ge_niels)); I.ipa_tabB.ensure((half > 1 ? half : 2) * sizeof(ge_niels));
-        I.scratch_ext.ensure(2 * half * sizeof(ge_ext));
         I.naf.ensure(4096);
     }
     Scalar Gamma = Scalar::one(), Eta = Scalar::one();
@@ -1118,10 +1234,10 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             }
             const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
             if (tt_wide) BPG_LAUNCH(I, k_tt_round8, dim3(nblk, 2), dim3(256), tt_wide, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j, I.tt_partial.as<ge_ext>());
-            else BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table.as<ge_pniels>(), a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
+            else BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table_p, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
                        I.tt_partial.as<ge_ext>());
             BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
-                       I.tt_table.as<ge_pniels>() + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
+                       I.tt_table_p + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
             HIPCHK(hipGetLastError());
             uint8_t lr[64];
             uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);       // L, R as extended points; encoded on the host
@@ -1197,6 +1313,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 fG[k - 1] = uk * uk; fH[k - 1] = ukinv * ukinv * yinv_pow2[ceil_log2(g_M >> k)];
             }
             ge_niels *dst = (g_index & 1) ? I.ipa_tabB.as<ge_niels>() : I.ipa_tabA.as<ge_niels>();
+            I.scratch_ext.ensure((size_t)2 * Mr * sizeof(ge_ext));         // the folded points before their normalisation (2^18 of them after the first group of three rounds at 2^20)
             // the group-start tables are the original generators: width-w NAF against their precomputed odd multiples (k_fold_points_wnaf) -
             // unless no table fits the budget of this device, in which case the register kernels below fold them
             const bool use_wnaf = I.fold_wnaf >= 3 && Gst == Gtab && Hst == Htab && Gtab == I.gens.as<ge_niels>() && 2 * Mr > I.fold_split_max
@@ -1461,18 +1578,30 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const bool chain_ready = bs && bs->produced.load(std::memory_order_acquire) >= 2 * n;
     const bool merged = expanded || tabled || n < 4096 || chain_ready;   // nothing to hide behind: A_I, A_O, S in one pass after the draws (one serial tail, not four)
     Impl::MsmTicket tk_aiao{0, 0, 0}, tk_s[3]; uint32_t nparts = 0;
+    // A_I's terms with equal scalars share their bucket entries (hip/k_merge.cuh): grouped once per uploaded witness, here at its first proof
+    if (!tabled) { if (I.merge_equal == 2) c->merge_tried = false; I.merge_witness(c, Gtab, Htab); }
+    I.merged_last = tabled ? 0u : c->mI.groups + c->mO.groups; I.merged_skipped_last = tabled ? 0u : c->mI.skipped + c->mO.skipped;
+    auto push_AI = [&](MsmSegs &S) {        // <a_L, G> + <a_R, H> + i_blinding * B_blinding as result 0
+        const bool mg = c->mI.groups != 0;
+        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0, 31, mg ? c->mI.skipA.as<uint32_t>() : nullptr);
+        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0, 31, mg ? c->mI.skipB.as<uint32_t>() : nullptr);
+        if (mg) { seg_push(S, c->mI.sc.as<scm>(), c->mI.pts.as<ge_niels>(), c->mI.groups, 0); I.msm_alg_discount += c->mI.groups; I.msm_skipped_terms += c->mI.skipped; }
+        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
+    };
+    auto push_AO = [&](MsmSegs &S) {        // <a_O, G> + o_blinding * B_blinding as result 1
+        const bool mg = c->mO.groups != 0;
+        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1, 31, mg ? c->mO.skipA.as<uint32_t>() : nullptr);
+        if (mg) { seg_push(S, c->mO.sc.as<scm>(), c->mO.pts.as<ge_niels>(), c->mO.groups, 1); I.msm_alg_discount += c->mO.groups; I.msm_skipped_terms += c->mO.skipped; }
+        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+    };
     if (!merged) {
         MsmSegs S = seg_new();
-        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
-        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
-        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
-        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
-        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+        push_AI(S); push_AO(S);
         tk_aiao = I.msm(S, 2);
     }
     const double t_rng0 = now_ms();
-    I.h_raw.ensure((2 * n ? 2 * n : 1) * 64);
-    I.raw_rng.ensure((2 * n ? 2 * n : 1) * 64); I.sLR.ensure((2 * n ? 2 * n : 1) * sizeof(scm));
+    if (!bs && !expanded) { I.h_raw.ensure((2 * n ? 2 * n : 1) * 64); I.raw_rng.ensure((2 * n ? 2 * n : 1) * 64); }      // the draws of a chain made inside this call; a blinding stream brings its own slabs
+    I.sLR.ensure((2 * n ? 2 * n : 1) * sizeof(scm));
     scm *sL = I.sLR.as<scm>(), *sR = sL + n;
     // S = <s_L, G> + <s_R, H> + sb * B_blinding is accumulated in pieces as the draws arrive: <s_L, G> once s_L is complete,
     // the first 7/8 of <s_R, H> next, and only the last eighth (+ the blinding term) after the chain has ended.
@@ -1560,7 +1689,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     uint8_t pts[96];
     if (tabled) {
         const uint32_t M0 = (uint32_t)N, nblk = cdiv((uint64_t)M0 * 16, 256);
-        BPG_LAUNCH(I, k_tt_commit3, dim3(nblk, 3), dim3(256), I.tt_table.as<ge_pniels>(), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR,
+        BPG_LAUNCH(I, k_tt_commit3, dim3(nblk, 3), dim3(256), I.tt_table_p, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR,
                    (uint32_t)n, M0, I.tt_partial.as<ge_ext>());
         BPG_LAUNCH(I, k_tt_commit3_finish, dim3(3), dim3(256), I.tt_partial.as<ge_ext>(), nblk, I.extras.as<scm>(),
                    I.ped_table.as<ge_pniels>() + (size_t)TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
@@ -1571,11 +1700,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         for (int k = 0; k < 3; k++) h51::pt_compress(pts + 32 * k, h51::pt_from_device(hp + 32 * k));
     } else if (merged) {
         MsmSegs S = seg_new();
-        seg_push(S, c->aL.as<scm>(), Gtab, (uint32_t)n, 0);
-        seg_push(S, c->aR.as<scm>(), Htab, (uint32_t)n, 0);
-        seg_push(S, I.extras.as<scm>() + 0, Bbn, 1, 0);
-        seg_push(S, c->aO.as<scm>(), Gtab, (uint32_t)n, 1);
-        seg_push(S, I.extras.as<scm>() + 1, Bbn, 1, 1);
+        push_AI(S); push_AO(S);
         seg_push(S, sL, Gtab, (uint32_t)n, 2);
         seg_push(S, sR, Htab, (uint32_t)n, 2);
         seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
@@ -1607,23 +1732,27 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const Scalar yinv = y.invert();
 
     // ---- powers, flattened weights, t-polynomial
-    I.ypow.ensure(N * sizeof(scm)); I.yinvpow.ensure(N * sizeof(scm)); I.zpow.ensure((q + 2) * sizeof(scm));
-    I.wAll.ensure((c->ncols ? c->ncols : 1) * sizeof(scm));
+    // y^-i stays for the inner-product argument; y^i, z^j and the flattened weights are needed until k_poly_eval only: they take the arena between the
+    // S sums (synchronised above) and the first multiscalar sum of the inner-product argument
+    I.yinvpow.ensure(N * sizeof(scm));
+    const size_t b_w = Impl::al256((c->ncols ? c->ncols : 1) * sizeof(scm)), b_z = Impl::al256((q + 2) * sizeof(scm)), b_y = Impl::al256(N * sizeof(scm));
+    I.arena.ensure(b_w + b_z + b_y);
+    scm *const wAll_p = reinterpret_cast<scm *>(I.arena_at(0)), *const zpow_p = reinterpret_cast<scm *>(I.arena_at(b_w)), *const ypow_p = reinterpret_cast<scm *>(I.arena_at(b_w + b_z));
     auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
         uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
         BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
     };
-    exp_table(y, I.ypow.as<scm>(), N);
+    exp_table(y, ypow_p, N);
     exp_table(yinv, I.yinvpow.as<scm>(), N);
-    exp_table(z, I.zpow.as<scm>(), q + 1);
+    exp_table(z, zpow_p, q + 1);
     if (c->ncols > 1)      // every column but the last (constant terms: verifier only)
         BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
-                           c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
-    scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;
+                           c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), zpow_p, wAll_p, (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
+    scm *wL = wAll_p, *wR = wL + n, *wO = wR + n, *wV = wO + n;
     const uint32_t pblocks = n ? std::min<uint32_t>(cdiv(n, 256), 1024) : 1;
     I.red_partial.ensure((size_t)pblocks * 6 * sizeof(scm) + 4096); I.red_out.ensure(16 * sizeof(scm));
     BPG_LAUNCH(I, k_poly_t, dim3(pblocks), dim3(256), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
-                       I.ypow.as<scm>(), I.yinvpow.as<scm>(), I.red_partial.as<scm>(), (uint32_t)n);
+                       ypow_p, I.yinvpow.as<scm>(), I.red_partial.as<scm>(), (uint32_t)n);
     BPG_LAUNCH(I, k_reduce_partials, dim3(6), dim3(256), I.red_partial.as<scm>(), pblocks, 6u, I.red_out.as<scm>());
     HIPCHK(hipGetLastError());
     scm h_t[6]; std::vector<scm> h_wV(m ? m : 1);
@@ -1659,7 +1788,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
 
     I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm));
     BPG_LAUNCH(I, k_poly_eval, dim3(cdiv(N, 256)), dim3(256), c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR, wL, wR, wO,
-                       I.ypow.as<scm>(), I.yinvpow.as<scm>(), to_scm(x), I.lv.as<scm>(), I.rv.as<scm>(), (uint32_t)n, (uint32_t)N);
+                       ypow_p, I.yinvpow.as<scm>(), to_scm(x), I.lv.as<scm>(), I.rv.as<scm>(), (uint32_t)n, (uint32_t)N);
     HIPCHK(hipGetLastError());
     lap(tm ? &tm->poly : nullptr);
 
@@ -1741,21 +1870,25 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
     I.vfy_sc.ensure((size_t)(npts + 2) * sizeof(scm)); I.vfy_ch.ensure(sizeof(IpaChallenges));
     HIPCHK(hipMemcpyAsync(I.vfy_in.p, hpts.data(), hpts.size(), hipMemcpyHostToDevice, st));
     BPG_LAUNCH(I, k_decompress, dim3(cdiv(npts, 64)), dim3(64), I.vfy_in.as<uint8_t>(), I.vfy_pts.as<ge_niels>(), I.vfy_ok.as<uint32_t>(), npts);
-    I.yinvpow.ensure(N * sizeof(scm)); I.zpow.ensure((q + 2) * sizeof(scm)); I.wAll.ensure(c->ncols * sizeof(scm));
+    I.yinvpow.ensure(N * sizeof(scm));
+    // powers of z, the flattened weights and the s vector are read by k_verify_scalars and earlier kernels only: in the arena, ahead of the one MSM
+    const size_t b_w = Impl::al256(c->ncols * sizeof(scm)), b_z = Impl::al256((q + 2) * sizeof(scm)), b_y = Impl::al256(N * sizeof(scm));
+    I.arena.ensure(b_w + b_z + b_y);
+    scm *const wAll_p = reinterpret_cast<scm *>(I.arena_at(0)), *const zpow_p = reinterpret_cast<scm *>(I.arena_at(b_w)), *const ypow_p = reinterpret_cast<scm *>(I.arena_at(b_w + b_z));
     auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
         uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
         BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
     };
     exp_table(yinv, I.yinvpow.as<scm>(), N);
-    exp_table(z, I.zpow.as<scm>(), q + 1);
+    exp_table(z, zpow_p, q + 1);
     if (c->ncols > 1)
         BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(),
-                   c->coef.as<scm>(), I.zpow.as<scm>(), I.wAll.as<scm>(), (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
-    scm *wL = I.wAll.as<scm>(), *wR = wL + n, *wO = wR + n, *wV = wO + n;      // wV[m] = w_c
+                   c->coef.as<scm>(), zpow_p, wAll_p, (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
+    scm *wL = wAll_p, *wR = wL + n, *wO = wR + n, *wV = wO + n;      // wV[m] = w_c
     {   // w_c: grid-wide reduction over the constant-term entries
         const uint64_t e0 = c->const_begin, e1 = c->nnz;
         const uint32_t cb = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(e1 - e0, 256), 512));
-        BPG_LAUNCH(I, k_flatten_const, dim3(cb), dim3(256), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), I.zpow.as<scm>(), e0, e1,
+        BPG_LAUNCH(I, k_flatten_const, dim3(cb), dim3(256), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), zpow_p, e0, e1,
                    I.red_partial.as<scm>() + 1024);
         BPG_LAUNCH(I, k_reduce_partials, dim3(1), dim3(256), I.red_partial.as<scm>() + 1024, cb, 1u, wV + m);
     }
@@ -1765,8 +1898,8 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
         for (uint32_t k = 0; k < lgN; k++) { hc->u[k] = to_scm(uk[k]); hc->uinv[k] = to_scm(ukinv[k]); }
         HIPCHK(hipMemcpyAsync(I.vfy_ch.p, hc, sizeof(IpaChallenges), hipMemcpyHostToDevice, st));
     }
-    I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm)); I.ypow.ensure(N * sizeof(scm));
-    scm *svec = I.ypow.as<scm>(), *gsc = I.lv.as<scm>(), *hsc = I.rv.as<scm>();
+    I.lv.ensure(N * sizeof(scm)); I.rv.ensure(N * sizeof(scm));
+    scm *svec = ypow_p, *gsc = I.lv.as<scm>(), *hsc = I.rv.as<scm>();
     BPG_LAUNCH(I, k_ipa_s, dim3(cdiv(N, 256)), dim3(256), I.vfy_ch.as<IpaChallenges>(), svec, lgN, (uint32_t)N);
     const uint32_t blocks = std::min<uint32_t>(cdiv(N, 256), 1024);
     BPG_LAUNCH(I, k_verify_scalars, dim3(blocks), dim3(256), wL, wR, wO, I.yinvpow.as<scm>(), svec, to_scm(x), to_scm(ipa), to_scm(ipb), to_scm(u_ch),

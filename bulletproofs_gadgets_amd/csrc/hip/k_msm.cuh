@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 
 // Sorting the (term, window) entries by bucket without global atomics (device-scope atomics on MI355X resolve beyond the per-XCD L2 and
 // were the slowest part of the MSM): LDS histograms and LDS-staged runs only, see "two-level sort" below.
-// key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg << 27 | index-in-segment.
+// key = (msm * W + window) * nb + (|digit| - 1); entry = sign << 31 | seg (4 bits) << 27 | index-in-segment.
 // Signed digits come from a carry-free recoding: with bias = sum_j 2^(off(j)+wd(j)-1) added to the scalar once, digit j is
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
@@ -54,7 +54,7 @@ __device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, c
 //   k_msm_count1    block (tile of 2^lgTile terms, window): LDS histogram over the CB coarse bins (top bits of the bucket index)
 //   (scan)          exclusive scan of counts1[(msm*W + window)*CB + bin][tile] in that order: where each (bin, tile) run starts
 //   k_msm_scatter1  block (tile, window): orders its entries by coarse bin in LDS and copies the runs out - consecutive lanes write
-//                   consecutive addresses; entry = neg << 31 | fine << (31 - fb) | segment << (28 - fb) | index in segment
+//                   consecutive addresses; entry = neg << 31 | fine << (31 - fb) | segment << (27 - fb) | index in segment
 //   k_msm_sort2     block per coarse bin: counting sort by the fb fine bits inside the bin's own range (LDS counters, the range is written
 //                   by this block only, so its lines are completed in the XCD's L2), emits starts[] per bucket
 // The result is exactly what the one-level sort produces (entries grouped by bucket, starts[]); the sweep is unchanged.
@@ -79,6 +79,11 @@ __global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32
     if (g == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
     if (g >= total) return;
     const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    const uint32_t *skip = S.skip[s];
+    if (skip && ((skip[i >> 5] >> (i & 31u)) & 1u)) {         // merged away (its scalar rides on another term of this sum): no entry in any window
+        for (uint32_t j = 0; j < P.W; j++) dig[(size_t)j * total + g] = (uint16_t)32768;
+        return;
+    }
     uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
     for (uint32_t j = 0; j < P.W; j++) {
         dig[(size_t)j * total + g] = (uint16_t)(msm_digit_biased(w, P.W, j) + 32768);
@@ -152,14 +157,17 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
         __syncthreads();
     }
     const uint32_t fmask = (1u << P.fb) - 1u;
+    const uint32_t sfirst = msm_find_seg(S, g0), slast = msm_find_seg(S, g1 - 1u);      // wave-uniform: the segments this tile touches (nearly always one)
 #pragma unroll
     for (uint32_t it = 0; it < MSM_TILE1_PER; it++) {
         const uint32_t g = g0 + it * 256u + threadIdx.x;
         const uint32_t d = keep[it] & 0xffffu, mag = msm_dig_mag(d);
         if (mag) {
             const uint32_t bkt = mag - 1u, bin = bkt >> P.fb, pos = lbase[bin] + (keep[it] >> 16);
-            const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-            staged[pos] = (msm_dig_neg(d) << 31) | ((bkt & fmask) << (31u - P.fb)) | (s << (28u - P.fb)) | i;
+            uint32_t s = sfirst;
+            for (uint32_t k = sfirst + 1; k <= slast; k++) if (g >= S.start[k]) s = k;
+            const uint32_t i = g - S.start[s];
+            staged[pos] = (msm_dig_neg(d) << 31) | ((bkt & fmask) << (31u - P.fb)) | (s << (27u - P.fb)) | i;
             sbin[pos] = (uint16_t)bin;
         }
     }
@@ -207,7 +215,7 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
         if (k + 1 == K && lane == 0) starts[(size_t)K * nf] = s1;
     }
     __syncthreads();
-    const uint32_t idxbits = 28u - P.fb, imask = (1u << idxbits) - 1u;
+    const uint32_t idxbits = 27u - P.fb, imask = (1u << idxbits) - 1u;
     for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
         uint32_t vv[4];
 #pragma unroll
@@ -218,7 +226,7 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
             const bool on = e < s1;
             const uint32_t v = vv[u], f = (v >> fsh) & fmask;
             const uint32_t pos = stash ? (on ? cur[f] + slot16[e - s0] : 0u) : msm_lds_take(cur, f, on);
-            if (on) entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 7u) << 27) | (v & imask);
+            if (on) entries[pos] = (v & 0x80000000u) | (((v >> idxbits) & 15u) << 27) | (v & imask);
         }
     }
 }
@@ -285,13 +293,13 @@ __device__ __forceinline__ uint32_t msm_bucket_of(const uint32_t *__restrict__ s
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (starts[mid] <= e) lo = mid + 1; else hi = mid; }
     return lo - 1;
 }
-// q = +-P for the affine Niels point at `base` (y+x, y-x, 2dxy): a subtraction exchanges the first two (picked by ADDRESS: no select) and
+// q = +-P for the (halved) affine Niels point at `base` ((y+x)/2, (y-x)/2, dxy): a subtraction exchanges the first two (picked by ADDRESS: no select) and
 // the sign of the third, which is the same as exchanging F and G of the addition formulas
 __device__ __forceinline__ ge_ext ge_madd_swapped(const ge_ext &p, const fe &qp, const fe &qm, const fe &t2d, uint32_t neg) {
     fe A = fe_mul(fe_sub(p.Y, p.X), qm);
     fe B = fe_mul(fe_add(p.Y, p.X), qp);
     fe C = fe_mul(p.T, t2d);
-    fe D = fe_add(p.Z, p.Z);
+    const fe &D = p.Z;                                         // halved Niels operand (ge.cuh): no doubling of Z
     fe E = fe_sub(B, A), F0 = fe_sub(D, C), G0 = fe_add(D, C), H = fe_add(B, A);
     const fe F = fe_select(F0, G0, neg), G = fe_select(G0, F0, neg);
     ge_ext r; r.X = fe_mul(E, F); r.Y = fe_mul(G, H); r.T = fe_mul(E, H); r.Z = fe_mul(F, G);
@@ -312,7 +320,7 @@ __global__ void __launch_bounds__(256) k_bucket_chunks(MsmSegs S, const uint32_t
     uint32_t ent = entries[e0];
     ge_ext acc = ge_identity();
     for (uint32_t e = e0; e < e1; e++) {
-        const uint32_t sg = (ent >> 27) & 7u, neg = ent >> 31;
+        const uint32_t sg = (ent >> 27) & 15u, neg = ent >> 31;
         const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
         const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];   // issued before the bookkeeping below
         if (e + 1 < e1) ent = entries[e + 1];
@@ -416,6 +424,128 @@ __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__
         ge_ext acc = buckets[k];
         for (uint32_t c = c0 + 2; c <= c1; c++) acc = ge_add(acc, slotA[c]);
         buckets[k] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bucket-major sweep (round 5)
+// The balanced sweep above cuts the sorted entry list into equal chunks, so every lane pays, entry after entry, for the possibility that its chunk
+// crosses a bucket boundary (with ~32 entries per bucket and 64 lanes a wave takes the boundary branch - stores, a reset of the accumulator, the next
+// bucket's limits - in six iterations out of seven), and the pieces of a bucket have to be joined afterwards (k_bucket_combine, its heavy list, 256 bytes
+// of partial sums per chunk).  Bucket lengths in a window are Poisson around total / 2^(c-1); what a lane-per-bucket sweep loses is only the SPREAD of
+// the lengths inside a wave.  So: a block takes KB = 256 * PER consecutive buckets, sorts them by length in LDS (a counting sort: lengths are below 256
+// here), and each wave sweeps 64 buckets of (nearly) equal length, one per lane, longest first - no boundary inside the loop, the bucket sum goes straight
+// to buckets[key], nothing to join.  2,048 buckets per block keep 98 % of the lane-iterations busy at 32 entries per bucket (98.6 % at 61).  Buckets of
+// 256 entries and more (thousands of identical scalars: range-proof bits, repeated witness values) are cut into parts of BSORT_PART entries for
+// k_bucket_heavy_parts (a LANE per part: the same loop, every lane 64 entries long) and k_bucket_heavy_join (a wave per bucket sums its parts).
+#define BSORT_LCAP 255u
+#define BSORT_PART 64u
+template <int PER> __global__ void __launch_bounds__(256) k_bucket_sorted(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
+                                                                           ge_ext *__restrict__ buckets, uint32_t nkeys,
+                                                                           uint32_t *__restrict__ heavy /* [0] buckets, [1] parts, then (key, first part) pairs */,
+                                                                           uint2 *__restrict__ partlist /* (key, part) per heavy part */) {
+    constexpr uint32_t KB = 256u * PER;
+    __shared__ uint32_t hist[256], base[256], wtot[4];
+    __shared__ uint32_t s_start[KB];
+    __shared__ uint16_t s_key[KB];
+    __shared__ uint8_t s_len[KB];
+    const uint32_t k0 = blockIdx.x * KB, kb = k0 + threadIdx.x * PER, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t st[PER + 1], slot[PER];
+#pragma unroll
+    for (int j = 0; j <= PER; j++) st[j] = starts[min(kb + (uint32_t)j, nkeys)];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t len = st[j + 1] - st[j];
+        slot[j] = 0;
+        if (len > BSORT_LCAP) {                                            // (keys past nkeys have len 0)
+            const uint32_t np = (len + BSORT_PART - 1u) / BSORT_PART;
+            const uint32_t h = atomicAdd(&heavy[0], 1u), p0 = atomicAdd(&heavy[1], np);
+            heavy[2 + 2 * h] = kb + j; heavy[3 + 2 * h] = p0;
+            for (uint32_t p = 0; p < np; p++) partlist[p0 + p] = make_uint2(kb + j, p);
+        } else if (len) slot[j] = atomicAdd(&hist[len], 1u);
+    }
+    __syncthreads();
+    {   // base[L] = buckets of this block that are LONGER than L: longest first.  A suffix scan over the 256 counters: waves by shuffles, then the wave totals
+        const uint32_t v = hist[threadIdx.x];
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(incl, d, 64); if (lane + d < 64) incl += o; }
+        if (lane == 0) wtot[wv] = incl;
+        __syncthreads();
+        uint32_t off = 0;
+        for (uint32_t k = wv + 1; k < 4; k++) off += wtot[k];
+        base[threadIdx.x] = off + incl - v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const uint32_t len = st[j + 1] - st[j];
+        if (len && len <= BSORT_LCAP) {
+            const uint32_t pos = base[len] + slot[j];
+            s_start[pos] = st[j]; s_key[pos] = (uint16_t)(threadIdx.x * PER + j); s_len[pos] = (uint8_t)len;
+        }
+    }
+    __syncthreads();
+    const uint32_t nn = base[0], groups = (nn + 63u) >> 6;                 // (hist[0] stays 0: base[0] counts every bucket swept here)
+    // groups are dealt to the four waves boustrophedon (0 1 2 3 | 3 2 1 0 | ...): the lengths fall from group to group, so each wave gets the same total
+    for (uint32_t r = 0; 4u * r < groups; r++) {
+        const uint32_t g = 4u * r + ((r & 1u) ? 3u - wv : wv);
+        if (g >= groups) continue;
+        const uint32_t idx = g * 64u + lane;
+        const bool valid = idx < nn;
+        const uint32_t len = valid ? s_len[idx] : 0u, e0 = valid ? s_start[idx] : 0u;
+        const uint32_t lmax = __builtin_amdgcn_readfirstlane(len);        // lane 0 holds the longest bucket of the group
+        uint32_t ent = len ? entries[e0] : 0u;
+        ge_ext acc = ge_identity();
+        for (uint32_t i = 0; i < lmax; i++) {
+            if (i < len) {
+                const uint32_t sg = (ent >> 27) & 15u, neg = ent >> 31;
+                const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
+                const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];
+                if (i + 1 < len) ent = entries[e0 + i + 1];
+                acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
+            }
+        }
+        if (valid) buckets[k0 + s_key[idx]] = acc;
+    }
+}
+// a lane per part of a heavy bucket (BSORT_PART entries, the last part of a bucket fewer): the loop of k_bucket_sorted without its prologue
+__global__ void __launch_bounds__(256) k_bucket_heavy_parts(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
+                                                            const uint32_t *__restrict__ heavy, const uint2 *__restrict__ partlist, ge_ext *__restrict__ hparts) {
+    const uint32_t gp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gp >= heavy[1]) return;
+    const uint2 kp = partlist[gp];
+    const uint32_t e0 = starts[kp.x] + kp.y * BSORT_PART, e1 = min(e0 + BSORT_PART, starts[kp.x + 1]);
+    uint32_t ent = entries[e0];
+    ge_ext acc = ge_identity();
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t sg = (ent >> 27) & 15u, neg = ent >> 31;
+        const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
+        const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];
+        if (e + 1 < e1) ent = entries[e + 1];
+        acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
+    }
+    hparts[gp] = acc;
+}
+// a wave per heavy bucket: its parts summed lane-strided, then a tree over the wave through LDS
+__global__ void __launch_bounds__(256) k_bucket_heavy_join(const uint32_t *__restrict__ starts, const uint32_t *__restrict__ heavy, const ge_ext *__restrict__ hparts,
+                                                           ge_ext *__restrict__ buckets) {
+    __shared__ ge_ext lds[256];
+    const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    ge_ext *L = lds + wv * 64;
+    for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {       // wave-uniform trip count; no block barrier inside
+        const uint32_t k = heavy[2 + 2 * it], p0 = heavy[3 + 2 * it];
+        const uint32_t np = (starts[k + 1] - starts[k] + BSORT_PART - 1u) / BSORT_PART;
+        ge_ext acc = ge_identity();
+        for (uint32_t p = lane; p < np; p += 64) acc = ge_add(acc, hparts[p0 + p]);
+        L[lane] = acc;
+        for (uint32_t d = 32; d > 0; d >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < d) L[lane] = ge_add(L[lane], L[lane + d]);
+        }
+        if (lane == 0) buckets[k] = L[0];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 

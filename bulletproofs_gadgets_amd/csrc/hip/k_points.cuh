@@ -33,23 +33,22 @@ __device__ __forceinline__ fe quad_dbl(const fe &c, uint32_t r) {
     // X3 = cX * cT, Y3 = YpX * YmX, Z3 = YmX * cT, T3 = cX * YpX
     return fe_mul(quad_pick(r, cX, YpX, YmX, cX), quad_pick(r, cT, YmX, cT, YpX));
 }
-// mixed addition with an affine Niels operand spread over the quad: qv = (y - x, y + x, 2dxy, 2)[r]; neg subtracts instead
+// mixed addition with a (halved, ge.cuh) affine Niels operand spread over the quad: qv = ((y - x)/2, (y + x)/2, dxy, 1)[r]; neg subtracts instead
 // (the first two exchange, the third changes sign).  c = coordinate r of P -> coordinate r of P +- Q
 __device__ __forceinline__ fe quad_madd(const fe &c, const fe &qv, uint32_t neg, uint32_t r) {
     fe qs = fe_select(qv, quad_swap01(qv), neg);
     qs = fe_select(qs, fe_neg(qs), neg & (uint32_t)(r == 2u));
     const fe X1 = quad_get<0>(c), Y1 = quad_get<1>(c);
     const fe lhs = quad_pick(r, fe_sub(Y1, X1), fe_add(Y1, X1), quad_get<3>(c), quad_get<2>(c));      // (Y1 - X1, Y1 + X1, T1, Z1)[r]
-    const fe p = fe_mul(lhs, qs);                                                                   // A, B, C, D = 2 Z1
+    const fe p = fe_mul(lhs, qs);                                                                   // A, B, C, D = Z1
     const fe A = quad_get<0>(p), B = quad_get<1>(p), C = quad_get<2>(p), D = quad_get<3>(p);
     const fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
     // X3 = E * F, Y3 = G * H, Z3 = F * G, T3 = E * H
     return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
 }
 __device__ __forceinline__ fe quad_load_niels(const ge_niels *p, uint32_t r) {     // lane r's operand of quad_madd
-    const fe *f = reinterpret_cast<const fe *>(p);                                 // ge_niels = {y + x, y - x, 2dxy}
-    fe two = fe_zero(); two.v[0] = 2;
-    return r == 3u ? two : f[r == 0u ? 1 : (r == 1u ? 0 : 2)];
+    const fe *f = reinterpret_cast<const fe *>(p);                                 // ge_niels = {(y + x)/2, (y - x)/2, dxy}
+    return r == 3u ? fe_one() : f[r == 0u ? 1 : (r == 1u ? 0 : 2)];
 }
 
 // ------------------------------------------------------------------------------------------------ generators
@@ -78,15 +77,15 @@ __global__ void __launch_bounds__(256) k_normalize_niels(const ge_ext *__restric
         pre[k] = acc;
         if (idx < count) acc = fe_mul(acc, in[idx].Z);
     }
-    fe inv = fe_invert(acc);
+    fe inv = fe_mul(fe_invert(acc), FE_INV2());                // 1 / (2 Z_1 .. Z_K): the halved Niels form wants 1 / (2 Z_k), and the 1/2 rides along for nothing
 #pragma unroll
     for (int k = NORM_K - 1; k >= 0; k--) {
         uint32_t idx = t + k * T;
         if (idx < count) {
             ge_ext p = in[idx];
-            fe zinv = fe_mul(inv, pre[k]);
-            inv = fe_mul(inv, p.Z);
-            out[idx] = ge_to_niels(p, zinv);
+            fe zinv_half = fe_mul(inv, pre[k]);
+            inv = fe_mul(inv, p.Z);                            // 1 / (2 Z_1 .. Z_(k-1))
+            out[idx] = ge_to_niels_halfinv(p, zinv_half);
         }
     }
 }
@@ -114,13 +113,24 @@ __global__ void k_init_bases(const uint32_t *__restrict__ hash64, ge_niels *__re
 }
 
 // unit-test hook for the device field arithmetic (the inline-asm paths cannot be compiled for the host):
-// op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 chain (mixed ops on weakly reduced intermediates); inputs are raw 256-bit values
+// op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 chain (mixed ops on weakly reduced intermediates); inputs are raw 256-bit values;
+// op 6: the SCALAR Montgomery product sc_mont_mul(a, b) = a b / 2^256 mod l (sc.cuh device path), raw words out
 __global__ void __launch_bounds__(64) k_test_fe(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint8_t *__restrict__ out, uint32_t n, uint32_t op) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     fe x, y, r;
 #pragma unroll
     for (int k = 0; k < 8; k++) { x.v[k] = a[8 * i + k]; y.v[k] = b[8 * i + k]; }
+    if (op == 6) {
+        scm sa, sb;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { sa.v[k] = x.v[k]; sb.v[k] = y.v[k]; }
+        const scm sr = sc_mont_mul(sa, sb);
+        uint32_t *o = reinterpret_cast<uint32_t *>(out + 32 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) o[k] = sr.v[k];
+        return;
+    }
     switch (op) {
     case 0: r = fe_mul(x, y); break;
     case 1: r = fe_sq(x); break;

@@ -6,6 +6,8 @@
 //                                       k_bucket_combine(_per_bucket, _heavy), k_bucket_reduce, k_window_sums
 //                                       (bucket method: digits -> coarse partition in LDS -> fine counting sort -> balanced bucket sweep -> reductions;
 //                                       the 17 window sums are recombined and encoded on the host, host/fe51.hpp)
+//       equal scalars of a_L, a_R        k_merge_insert, k_merge_flags, k_merge_members, k_merge_sum (k_merge.cuh): terms of A_I that carry the same value share one
+//                                       bucket entry per window on the sum of their generators; once per uploaded witness
 //   a10 vector-polynomial phase         k_exp_table, k_flatten, k_poly_t, k_poly_eval, k_reduce_partials
 //   a11 inner-product argument          above 2^14 generators: k_ipa_prep, the MSM kernels, k_tt_advance, one generator fold per group of rounds -
 //                                       k_fold_points_wnaf on the original generators (tables of (2m+1) * 2^(64j) * P: k_odd_start(_ext), k_odd_step,
@@ -23,10 +25,11 @@
 
 namespace bpg {
 
-#define BPG_MAX_SEGS 8
+#define BPG_MAX_SEGS 16                 // 4 segment bits in a sorted entry (sign | segment | 27 index bits)
 struct MsmSegs {
     const scm *sc[BPG_MAX_SEGS];
     const ge_niels *pts[BPG_MAX_SEGS];
+    const uint32_t *skip[BPG_MAX_SEGS]; // optional bit per term: 1 = the term takes no part (its scalar was merged into another segment's term, k_merge_*); nullptr = none
     uint32_t len[BPG_MAX_SEGS];
     uint32_t start[BPG_MAX_SEGS + 1];   // prefix of len
     uint32_t msm[BPG_MAX_SEGS];
@@ -51,3 +54,4 @@ __device__ __forceinline__ uint32_t msm_point_index(const MsmSegs &S, uint32_t s
 #include "k_ipa.cuh"
 #include "k_verify.cuh"
 #include "k_msm.cuh"
+#include "k_merge.cuh"

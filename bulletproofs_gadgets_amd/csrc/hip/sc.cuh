@@ -33,6 +33,66 @@ BPG_HD scm sc_cond_sub(const uint32_t t[9]) {
 }
 
 // Montgomery product a*b/2^256 mod l; needs a*b < 2^256 * l (true when one operand < l); output canonical
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 device path (round 5).  The portable row-wise form below compiles to ~520 VALU instructions (every 32-bit limb widened into the MAD's 64-bit
+// addend pair); this one is product scanning twice over, on the column blocks of fe.cuh: first the 512-bit product t = a * b (64 multiply-adds), then
+// the Montgomery reduction column by column - u_k = t_k + sum_{i+j=k} m_i l_j, m_k = u_k * (-1/l) mod 2^32 - where l has only five non-zero limbs
+// (l_4 = l_5 = l_6 = 0), so 40 more multiply-adds.  One VALU pair per limb product (v_mad_u64_u32 + the v_addc that collects its carry): ~330
+// instructions.  tests/test_gpu_parity.py::test_device_field_ops (op 6) checks it against Python integers on the GPU.
+__device__ __forceinline__ void sc_mac0(uint64_t &lo, uint32_t &hi, uint32_t x) {                    // lo += x, hi = carry
+    uint64_t c; asm("v_mad_u64_u32 %0, %2, %3, 1, %0\n\tv_addc_co_u32_e64 %1, %2, 0, 0, %2" : "+v"(lo), "=&v"(hi), "=&s"(c) : "v"(x));
+}
+__device__ __forceinline__ void sc_mac(uint64_t &lo, uint32_t &hi, uint32_t x, uint32_t y) {         // (hi, lo) += x * y
+    uint64_t c; asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2" : "+v"(lo), "+v"(hi), "=&s"(c) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ scm sc_mont_mul(const scm &a, const scm &b) {
+    uint32_t t[16];
+    uint64_t lo = 0; uint32_t hi;
+    fe_col1(lo, hi, a.v[0], b.v[0]); t[0] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[0], b.v[1], a.v[1], b.v[0]); t[1] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[0], b.v[2], a.v[1], b.v[1], a.v[2], b.v[0]); t[2] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col4(lo, hi, a.v[0], b.v[3], a.v[1], b.v[2], a.v[2], b.v[1], a.v[3], b.v[0]); t[3] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col5(lo, hi, a.v[0], b.v[4], a.v[1], b.v[3], a.v[2], b.v[2], a.v[3], b.v[1], a.v[4], b.v[0]); t[4] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col6(lo, hi, a.v[0], b.v[5], a.v[1], b.v[4], a.v[2], b.v[3], a.v[3], b.v[2], a.v[4], b.v[1], a.v[5], b.v[0]); t[5] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col7(lo, hi, a.v[0], b.v[6], a.v[1], b.v[5], a.v[2], b.v[4], a.v[3], b.v[3], a.v[4], b.v[2], a.v[5], b.v[1], a.v[6], b.v[0]); t[6] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col8(lo, hi, a.v[0], b.v[7], a.v[1], b.v[6], a.v[2], b.v[5], a.v[3], b.v[4], a.v[4], b.v[3], a.v[5], b.v[2], a.v[6], b.v[1], a.v[7], b.v[0]); t[7] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col7(lo, hi, a.v[1], b.v[7], a.v[2], b.v[6], a.v[3], b.v[5], a.v[4], b.v[4], a.v[5], b.v[3], a.v[6], b.v[2], a.v[7], b.v[1]); t[8] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col6(lo, hi, a.v[2], b.v[7], a.v[3], b.v[6], a.v[4], b.v[5], a.v[5], b.v[4], a.v[6], b.v[3], a.v[7], b.v[2]); t[9] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col5(lo, hi, a.v[3], b.v[7], a.v[4], b.v[6], a.v[5], b.v[5], a.v[6], b.v[4], a.v[7], b.v[3]); t[10] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col4(lo, hi, a.v[4], b.v[7], a.v[5], b.v[6], a.v[6], b.v[5], a.v[7], b.v[4]); t[11] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col3(lo, hi, a.v[5], b.v[7], a.v[6], b.v[6], a.v[7], b.v[5]); t[12] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col2(lo, hi, a.v[6], b.v[7], a.v[7], b.v[6]); t[13] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    fe_col1(lo, hi, a.v[7], b.v[7]); t[14] = (uint32_t)lo; lo = (lo >> 32) | ((uint64_t)hi << 32);
+    t[15] = (uint32_t)lo;
+    // Montgomery reduction, product scanning: column k of t + m * l, with l_j != 0 only for j in {0, 1, 2, 3, 7}
+    const uint32_t L0 = 0x5cf5d3edu, L1 = 0x5812631au, L2 = 0xa2f79cd6u, L3 = 0x14def9deu, L7 = 0x10000000u;
+    uint32_t m[8], r[9];
+    lo = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        sc_mac0(lo, hi, t[k]);
+        if (k >= 1) sc_mac(lo, hi, m[k - 1], L1);
+        if (k >= 2) sc_mac(lo, hi, m[k - 2], L2);
+        if (k >= 3) sc_mac(lo, hi, m[k - 3], L3);
+        if (k >= 7) sc_mac(lo, hi, m[k - 7], L7);
+        m[k] = (uint32_t)lo * BPG_SC_NINV;
+        sc_mac(lo, hi, m[k], L0);                                         // the low word of the column is now zero
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+        sc_mac0(lo, hi, t[k]);
+        if (k - 1 <= 7) sc_mac(lo, hi, m[k - 1], L1);
+        if (k - 2 <= 7) sc_mac(lo, hi, m[k - 2], L2);
+        if (k - 3 <= 7) sc_mac(lo, hi, m[k - 3], L3);
+        if (k - 7 <= 7) sc_mac(lo, hi, m[k - 7], L7);
+        r[k - 8] = (uint32_t)lo;
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+    }
+    r[8] = (uint32_t)lo;                                                  // (t + m l) / 2^256 < 2 l
+    return sc_cond_sub(r);
+}
+#else
 BPG_HD scm sc_mont_mul(const scm &a, const scm &b) {
     const scm L = SC_L();
     uint32_t t[10];
@@ -58,6 +118,7 @@ BPG_HD scm sc_mont_mul(const scm &a, const scm &b) {
     }
     return sc_cond_sub(t);
 }
+#endif
 
 BPG_HD scm sc_add(const scm &a, const scm &b) {
     uint32_t t[9]; uint64_t c = 0;

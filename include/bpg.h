@@ -173,7 +173,8 @@ bpg_status bpg_profile_set(bpg_ctx *ctx, int32_t mode);
 bpg_status bpg_profile_report(bpg_ctx *ctx, char *out, uint64_t cap);
 bpg_status bpg_bench_fe_mul(bpg_ctx *ctx, uint32_t iters, double *mults_per_second);
 
-/* test hook: device field arithmetic on n pairs of raw 256-bit values; op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 mixed chain; canonical output */
+/* test hook: device field arithmetic on n pairs of raw 256-bit values; op 0 mul, 1 sq, 2 add, 3 sub, 4 invert, 5 mixed chain; canonical output;
+ * op 6: the scalar-field Montgomery product a b / 2^256 mod l of the device (one operand below l), eight raw words out */
 bpg_status bpg_test_fe_ops(bpg_ctx *ctx, int32_t op, uint64_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 /* test hook: the next blinding stream started on ctx (bpg_blinding_begin) records a failed upload of its first block, as a failing hipMemcpyAsync
  * would: the prove that adopts it must fail with BPG_ERR_DEVICE instead of reading a stale device slab */

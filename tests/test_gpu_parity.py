@@ -105,6 +105,16 @@ def test_device_field_ops(ctx):
             x = (y - t) ** 2 % P
             y = (t - x) % P
         assert int.from_bytes(g, "little") == (x + y) % P
+    # op 6: the scalar field's Montgomery product (sc.cuh device path: product scanning + Montgomery reduction on l's five non-zero limbs);
+    # contract: one operand below l, the other any 256-bit value
+    Lq = R.L
+    Rinv = pow(2**256, -1, Lq)
+    sedge = [0, 1, 2, Lq - 1, Lq - 2, 2**252, 2**252 - 1, 2**128, (Lq - 1) // 2, 2**32 - 1, 2**64, 0x0fffffffffffffffffffffffffffffffffffffffffffffffffffffffffffffff]
+    sa = sedge + [int.from_bytes(hashlib.sha256(b"sa%d" % i).digest(), "little") % Lq for i in range(300)]
+    sb = [2**256 - 1, 2**256 - 2**32, Lq, Lq + 1, 2 * Lq, 0, 1, Lq - 1, 2**255, 2**253, 3, 2**256 - Lq] + [int.from_bytes(hashlib.sha256(b"sb%d" % i).digest(), "little") for i in range(300)]
+    got = ctx.test_fe_ops(6, [v.to_bytes(32, "little") for v in sa], [v.to_bytes(32, "little") for v in sb])
+    for x, y, g in zip(sa, sb, got):
+        assert int.from_bytes(g, "little") == x * y * Rinv % Lq, (hex(x), hex(y))
 
 
 def test_pedersen_bases_and_commitments(ctx, golden):
@@ -204,6 +214,45 @@ def test_msm_epilogue_and_sweep_knobs_give_the_oracle_sum(env, monkeypatch):
                 assert c.msm_gens(3, s, t) == O.msm(b"".join(s + t), G + Hh, 1), (env, cmin, count)
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("merge", ["1", "0", "2"])
+def test_equal_scalar_merging_changes_no_byte(merge, monkeypatch):
+    """Terms of A_I that carry the same scalar share one bucket entry per window on the sum of their generators (hip/k_merge.cuh; a MiMC round wires
+    a_L[2i] = a_R[2i] = a_R[2i+1], reference src/mimc_hash/mimc_hash_gadget.rs:133-144): grouped by value once per uploaded witness.  With the merging
+    on and off (BPG_MERGE), on circuits with groups of two, three, eight, nine, forty and hundreds of members (range-proof bits; groups beyond 1,024
+    members are summed in parts) and with zero scalars (never grouped), the proof is the oracle's, byte for byte.  BPG_TT_LG=0 sends these small circuits down the
+    bucket-method path that the full-size ones take."""
+    monkeypatch.setenv("BPG_MERGE", merge)
+    monkeypatch.setenv("BPG_TT_LG", "0")
+    c = bpg.Context(0)
+    try:
+        a = workloads.mimc_preimage(c, nbytes=100, seed=21, label=b"MiMCHash")
+        check_against_oracle(c, a.prover, a.transcript, a.commitments, a.gens_capacity, flags_list=(0, 1))
+        sch = c.schedule()
+        assert sch["merge_equal"] == int(merge)                                   # (2: grouped afresh in every proof)
+        n = a.prover.get_num_multiplications()
+        assert sch["merged_last"] == (0 if merge == "0" else n // 2), sch        # one group {a_L[2i], a_R[2i], a_R[2i+1]} per MiMC round of A_I; a_O = t^2, t^3: none
+        assert sch["merged_skipped_last"] == (0 if merge == "0" else 3 * (n // 2))
+        a = workloads.bounds_check_64(c, seed=22)                                # hundreds of equal bits: a few large groups
+        check_against_oracle(c, a.prover, a.transcript, a.commitments, a.gens_capacity)
+        # a hand-made witness: multipliers (x, y) with x drawn from a few values so that the value classes have 2, 3, 8, 9 and 40 members, some zero
+        t = bpg.Transcript(b"merge")
+        p = bpg.Prover(c, t)
+        vals = [rs(b"mv", k) for k in range(6)]
+        sizes = {0: 2, 1: 3, 2: 8, 3: 9, 4: 40}
+        for k, cnt in sizes.items():
+            for j in range(cnt):
+                p.allocate_multiplier((vals[k], rs(b"my", 100 * k + j)))           # a_L = the class value, a_R distinct
+        for j in range(5):
+            p.allocate_multiplier((bytes(32), rs(b"mz", j)))                       # zero scalars: no entries, never a group
+        l, r, o = p.allocate_multiplier((vals[5], vals[5]))                        # a_L[i] == a_R[i]: a group across the two halves
+        p.constrain(bpg.LinearCombination.of(l) - r)                               # (one constraint, satisfied: left = right)
+        check_against_oracle(c, p, t, [], 128)
+        if merge != "0":
+            assert c.schedule()["merged_last"] == 6                                # the five value classes of a_L and the (x, x) pair; a_O = x y: all different
+    finally:
+        c.close()
 
 
 def test_deferred_commitments_equal_one_launch_per_commitment(ctx):

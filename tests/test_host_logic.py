@@ -360,6 +360,20 @@ def test_host_thread_planning_on_synthetic_topologies():
     assert [len(bench.plan_chain_pool(16, n)) for n in (20, 10, 6)] == [14, 10, 6]
     assert [sum(bench.plan_chain_pool(16, n)) for n in (20, 10, 6)] == [20, 10, 6]
     assert 8 * len(bench.plan_chain_pool(16, 20)) == 112 and 8 * (len(bench.plan_chain_pool(16, 20)) + 2) <= 128
+    # `bench.py --gpus 8 --plan-only` (no GPU call): the same planner over the whole node, with the memory model of the engine's allocations - eight ranks of
+    # twenty streams fit a 288 GB card each and their pinned slabs fit the host RAM the planner is told about, under both profiles
+    for profile in ("serving", "oneshot"):
+        plan = bench.plan_node(8, 20, 20, profile, bench.synthetic_topology(8, numa_nodes=2, cores_per_node=64, host_ram_GB=1536.0))
+        assert plan["fits"] == {"hbm_per_card": True, "pinned_host": True, "a_core_per_chain_thread": True}
+        assert [r["numa_node"] for r in plan["ranks"]] == [0] * 4 + [1] * 4 and all(r["chain_pool_lanes"] == [1] * 13 + [7] for r in plan["ranks"])
+        assert all(r["hbm_expected_GB"] < 288 for r in plan["ranks"]) and plan["pinned_host_total_GB"] < 0.5 * 1536
+    one, srv = bench.memory_model(993384, 1 << 20, 1986769, 512, "oneshot", 20), bench.memory_model(993384, 1 << 20, 1986769, 512, "serving", 20)
+    assert one["hbm_GB"] <= 40.0 < srv["hbm_GB"] < 100.0 and abs((srv["hbm_GB"] - one["hbm_GB"]) - 240 * 2 * (1 << 20) * 96 / 1e9) < 0.01
+    # a host with 256 GB of RAM and a 64-CPU quota: the pinned slabs of 8 x 20 streams (43.5 GB) still fit, but a chain thread no longer gets a core
+    tight = bench.plan_node(8, 20, 20, "serving", bench.synthetic_topology(8, cores_per_node=64, host_ram_GB=256.0, cpu_quota=64))
+    assert tight["fits"]["pinned_host"] and all(r["cores_for_rank"] == 8 and sum(r["chain_pool_lanes"]) == 20 for r in tight["ranks"])
+    small = bench.plan_node(8, 20, 20, "serving", bench.synthetic_topology(8, host_ram_GB=64.0))
+    assert not small["fits"]["pinned_host"]
     for cores in range(1, 40):
         for n in (1, 2, 3, 8, 14, 20, 33):
             lanes = bench.plan_chain_pool(cores, n)
@@ -408,7 +422,7 @@ def test_config_struct_matches_the_header_and_pool_api_without_a_gpu(tmp_path):
     assert e.value.status in (4, 7)
 
 
-@pytest.mark.parametrize("var,val", [("BPG_RSEG", "0"), ("BPG_RSEG", "3"), ("BPG_RSEG", "abc"), ("BPG_RSEG", "2048"), ("BPG_RSEG", "8x"), ("BPG_LGCH", "1"), ("BPG_LGCH", "zz"),
+@pytest.mark.parametrize("var,val", [("BPG_MERGE", "3"), ("BPG_MERGE", "yes"), ("BPG_RSEG", "0"), ("BPG_RSEG", "3"), ("BPG_RSEG", "abc"), ("BPG_RSEG", "2048"), ("BPG_RSEG", "8x"), ("BPG_LGCH", "1"), ("BPG_LGCH", "zz"),
                                      ("BPG_SWEEP_RESIDENT", "0"), ("BPG_MSM_CMAX", "17"), ("BPG_MSM_CMIN", ""), ("BPG_FOLD_GROUP", "6"), ("BPG_FOLD_WNAF", "2"),
                                      ("BPG_FOLD_PARTS", "3"), ("BPG_TT_LG", "-1"), ("BPG_TABLE_GB", "-4"), ("BPG_FOLD_TABLE_GB", "nan"), ("BPG_CHAIN_LANES", "9"),
                                      ("BPG_SYNC_BLOCKING", "2"), ("BPG_FOLD_ADAPT", "3")])
