@@ -32,7 +32,7 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 METRIC = "R1CS constraints/sec (prove), 2^20-constraint MiMC-Merkle, 1/2/4/8 GPU"
-SWEEPS = ("k_bucket_sorted", "k_bucket_chunks")            # the bucket sweep's two shapes (csrc/hip/k_msm.cuh): shared device / proof alone
+SWEEPS = ("k_bucket_chunks",)                              # the bucket sweep (csrc/hip/k_msm.cuh)
 ENGINE = {"profile": "serving", "blocking_sync": True}       # bpg_config of every engine context (include/bpg.h bpg_ctx_create_ex)
 
 
@@ -202,9 +202,9 @@ def memory_model(n, N, q, m, profile, streams, nnz=None, merged_terms=0):
     W, nb = 16, 1 << 15                                         # shared-device windows: 16 bits (17 x 2^14 for a proof alone: the same bytes within 6 %)
     al = lambda x: (x + 255) & ~255
 
-    def msm_arena(total, live, sorted_sweep=True):
+    def msm_arena(total, live):
         mub = live * W
-        slots = ((mub // 64) + (mub // 256) + 1) * P_EXT if sorted_sweep else -(-mub // 34) * 2 * P_EXT
+        slots = -(-mub // 34) * 2 * P_EXT                        # two partial sums per chunk of the sweep; 34-entry chunks (a proof alone), 64 while the device is shared
         return max(al(total * W * 2) + al(live * W * 4), al(slots)) + al(live * W * 4)
     # device-wide, shared by the contexts of the process: [G | H] and the odd multiples of the first fold
     gens = 2 * N * P_NIELS
@@ -415,6 +415,51 @@ def in_flight_throughput(bpg, ctx0, res0, inst, state, capacity, device, n_ctx, 
             "unit": "constraints/s", "whole_run": {"value": inst.q * n_ctx * steps / dt, "ms_per_proof": dt / (n_ctx * steps) * 1e3},
             "host_threads": {"chain": n_ctx * workers, "lanes_per_chain_thread": lanes, "proving": n_ctx},
             "rate": "proofs completed after the first %d completions / time from that completion to the last" % skip}
+
+
+def throughput_variants(bpg, workloads, device, inst0, state0, capacity, n_ctx, steps, workers, lanes, leaves):
+    """The throughput leg once more under the settings that say where the equal-scalar merging of A_I / A_O (csrc/hip/k_merge.cuh) gets its gain:
+      merge_per_proof           BPG_MERGE=2: the grouping is redone inside EVERY proof (a host that proves each witness once pays that)
+      no_merging                BPG_MERGE=0: term by term, as round 4 proved
+      distinct_leaves(_no_merging)  the same tree over 512 DIFFERENT seeded leaves: only the wiring of a MiMC round repeats a value (43 % of A_I's terms merge)
+    The reference's own instance (`value`, `throughput`) hashes 512 EQUAL leaves (merkle_tree_gadget.rs:476-520): its 2.98 M terms of A_I and A_O carry ~35 k
+    distinct scalars.  Same proof bytes under every setting (tests/test_gpu_parity.py::test_equal_scalar_merging_changes_no_byte)."""
+    out = {}
+    distinct = None
+    for name, env, seeded in (("merge_per_proof", "2", False), ("no_merging", "0", False), ("distinct_leaves", None, True), ("distinct_leaves_no_merging", "0", True)):
+        old = os.environ.get("BPG_MERGE")
+        try:
+            if env is not None:
+                os.environ["BPG_MERGE"] = env
+            c = bpg.Context(device, **ENGINE)
+            try:
+                if seeded:
+                    if distinct is None:
+                        a = workloads.merkle_full_tree(c, leaves=leaves, seed=7)
+                        distinct = (a.prover.instance(), a.transcript.state)
+                    inst, state = distinct
+                else:
+                    inst, state = inst0, state0
+                c.gens_ensure(capacity)
+                res = c.upload(inst)
+                res.prove(state, inst.v_blinding, bytes(32), 0)
+                sch = c.schedule()
+                r = in_flight_throughput(bpg, c, res, inst, state, capacity, device, n_ctx, steps, workers=workers, lanes=lanes)
+                out[name] = {"ms_per_proof": r["ms_per_proof"], "value": r["value"], "proofs": r["proofs"], "merged_groups": sch["merged_last"],
+                             "terms_merged_away": sch["merged_skipped_last"], "merge_ms": sch["merge_ms_last"]}
+                res.free()
+            finally:
+                c.close()
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": repr(e)}
+        finally:
+            if old is None:
+                os.environ.pop("BPG_MERGE", None)
+            else:
+                os.environ["BPG_MERGE"] = old
+    out["note"] = ("sustained ms per proof of the throughput leg (%d streams x %d proofs) under BPG_MERGE=2 / 0 and on a tree of distinct leaves; merge_ms = wall time of one "
+                   "grouping of A_I and A_O (hash table, scans, one point addition per merged-away term, normalisation)" % (n_ctx, steps))
+    return out
 
 
 def file_config(ctx, workloads, which):
@@ -984,8 +1029,7 @@ def run_rank(args):
                     "note": "integer-VALU bound path (255-bit modular arithmetic): the HBM fraction is reported as required, the binding roofline is 'valu'; "
                             "kernel names as rocprofv3 prints them (profiles/*_kernel_stats.csv)",
                     "valu": dom["valu"], "whole_proof": whole, "other_kernels": [kernel_roofline(n) for n in ranked[1:]]}
-        # the bucket sweep exists in two shapes (csrc/hip/k_msm.cuh): balanced chunks for a proof alone on the device, bucket-major (length-sorted blocks) while
-        # other proofs share it; `iso_name` = the kernel that does a kernel's job in the single-stream leg
+        # `iso_name` = the kernel that does a kernel's job in the single-stream leg (the same name, unless a kernel has a shared-device shape of its own)
         def iso_name(n):
             if not prof_isolated:
                 return None
@@ -1006,8 +1050,7 @@ def run_rank(args):
             if iso["kernel"] != roofline["kernel"]:
                 roofline["traffic"], roofline["traffic_useful_fetch"] = iso["traffic"], iso["traffic_useful_fetch"]      # the counter passes profile one stream alone
                 roofline["kernel_alone"] = iso["kernel"]
-                roofline["note"] += ("; the sweep of a proof alone on the device is %s (balanced chunks), of a proof that shares it %s (a lane per bucket, buckets "
-                                     "sorted by length inside a block: fewest instructions) - same sums, `timed_steps_shared` holds the second" % (iso["kernel"], roofline["kernel"]))
+                roofline["note"] += "; alone on the device this kernel's job is done by %s" % iso["kernel"]
             roofline["other_kernels"] = [kernel_roofline(n, prof_isolated) for n in ranked[1:] if n in prof_isolated]
             roofline["measured"] = ("kernel alone on the GPU: HIP events on the engine's stream in the single-stream leg of this run (one proving stream, one "
                                     "chain thread; rocprofv3 --stats of that command: profiles/*_kernel_stats_single_stream.csv). `timed_steps_shared` = the "
@@ -1124,7 +1167,16 @@ def run_rank(args):
                         thr["hbm"]["traffic_source"] = "profiles/pmc_traffic_throughput.json was taken from other sources: not quoted"
                 except Exception as e:      # noqa: BLE001
                     thr["hbm"]["traffic_source"] = "profiles/pmc_traffic_throughput.json unreadable: %r" % (e,)
+            sch = ctx.schedule()
+            thr["merging"] = {"merged_groups": sch["merged_last"], "terms_merged_away": sch["merged_skipped_last"], "merge_ms_once_per_witness": sch["merge_ms_last"],
+                              "note": "A_I and A_O of this instance after the equal-scalar merging (csrc/hip/k_merge.cuh): groups of equal scalars and the terms they stand for; "
+                                      "grouped once per uploaded witness, outside the timed steps - `throughput_variants.merge_per_proof` has it inside every proof"}
             out["throughput"] = thr
+            try:
+                out["throughput_variants"] = throughput_variants(bpg, workloads, device_index, inst, state, a.gens_capacity, args.in_flight, max(2, args.in_flight_steps // 2),
+                                                                 max(1, args.in_flight_workers), max(1, min(8, args.in_flight_lanes)), args.leaves)
+            except Exception as e:      # noqa: BLE001
+                out["throughput_variants"] = {"error": repr(e)}
         except Exception as e:      # noqa: BLE001 - a failed secondary measurement must not lose the headline
             out["throughput"] = {"error": repr(e)}
     if multi_thr is not None:

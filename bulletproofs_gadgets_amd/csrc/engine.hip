@@ -208,7 +208,7 @@ struct DeviceCircuit {
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_blind_poison) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
     X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_sorted) X(k_bucket_heavy_parts) X(k_bucket_heavy_join) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr) X(k_merge_insert) X(k_merge_plan) X(k_merge_groups) X(k_merge_members) X(k_merge_sum)
 enum KernelId {
 #define X(n) KID_##n,
@@ -233,7 +233,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks || id == KID_k_bucket_sorted)); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -256,6 +256,23 @@ struct Engine::Impl {
     // (hipFree synchronises the device), exactly as growing any DevBuf does.
     DevBuf arena;
     uint8_t *arena_at(size_t off) const { return arena.as<uint8_t>() + off; }
+    // Waiting for the stream inside a proof (a round of the inner-product argument ends with one: the host needs L, R for the transcript).  With blocking waits
+    // (bpg_config.blocking_sync = 1: a host with many proving threads beside its chain threads) a wake-up costs tens of microseconds, twenty-odd times per
+    // proof; a proof that has the device to ITSELF has a core to spare, so it polls first (a proof alone: 1.5 ms; the mix never polls) and blocks only
+    // when the work is long.
+    bool blocking_waits = false;
+    void wait_stream() {
+        if (blocking_waits && !shared_now) {
+            const double until = now_ms() + 3.0;
+            do {
+                const hipError_t e = hipStreamQuery(st);
+                if (e == hipSuccess) return;
+                if (e != hipErrorNotReady) HIPCHK(e);
+                for (int k = 0; k < 64; k++) __builtin_ia32_pause();
+            } while (now_ms() < until);
+        }
+        HIPCHK(hipStreamSynchronize(st));
+    }
     static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
     // MSM workspace
     DevBuf counts, starts, cursor, blocksum, buckets, partial, msm_result, open_keys, medium, wsums, tile_hist, heavy, plain, starts1;   // tile_hist, plain: workspace of upload(); digits, the entry lists and the sweep's partial sums live in the arena
@@ -268,8 +285,6 @@ struct Engine::Impl {
     uint32_t profile = 1;           // 1 one-shot, 2 serving (what bpg_config / BPG_PROFILE settled on)
     bool shared_now = false;        // sampled ONCE per prove()/verify(): does this call take the shared-device variants (shared_variants())
     uint32_t msm_cmin = 2;          // BPG_MSM_CMIN: narrowest window (tests: wide windows on small sums)
-    uint32_t sweep_mode = 0;        // BPG_SWEEP: 0 balanced chunks (default: the bucket-major sweep measured slower in the mix), 1 bucket-major (length-sorted blocks) while the device is shared, 2 bucket-major always
-    uint32_t sweep_per = 8;         // BPG_SWEEP_PER: buckets per thread of a bucket-major block (2, 4, 8 or 16: 512 .. 4,096 buckets per block)
     uint32_t merge_equal = 1;       // BPG_MERGE: 0 A_I and A_O term by term; 1 equal scalars grouped once per uploaded witness (at its first proof); 2 grouped afresh in EVERY
                                     // proof (what a host that proves each witness once pays: the measurement behind bench.py's `merge_per_proof`); same bytes
     uint32_t merged_last = 0, merged_skipped_last = 0;   // witness of the last prove(): groups of equal scalars in A_I and A_O, and the terms they replace (0: none, or the table-driven path)
@@ -277,7 +292,7 @@ struct Engine::Impl {
     uint32_t msm_alg_discount = 0;  // terms of the next msm() call that are not terms of the sum it computes (merged-point terms stand in for terms that were skipped): roofline bookkeeping only
     void merge_witness(DeviceCircuit *c, const ge_niels *Gtab, const ge_niels *Htab);
     void merge_build(DeviceCircuit::MergeSet &M, const scm *A, const ge_niels *PA, uint32_t nA, const scm *B, const ge_niels *PB, uint32_t nB);
-    double merge_ms_last = 0;       // wall time of the last merge_witness() that did something (once per uploaded witness)
+    double merge_ms_last = 0;       // host wall time of the last merge_witness() that did something (BPG_MERGE=1: to the end of its kernels; 2: to the end of the group count's read-back)
     // prove buffers
     DevBuf sLR, yinvpow, lv, rv, red_partial, red_out, raw_rng, extras;      // (y^i, z^j and the flattened weights: in the arena)
     DevBuf stale_flag;              // one word, zero unless k_sc_from_wide met a poisoned (never uploaded) draw: checked before a proof leaves prove()
@@ -555,8 +570,6 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     // tuning knobs (diagnostics and the schedule tests; every setting gives the same bytes)
     if (env_present("BPG_MSM_CMAX")) K->msm_cmax = K->msm_cmax_shared = (uint32_t)env_int_strict("BPG_MSM_CMAX", 4, 16);
     env_set("BPG_MSM_CMIN", 2, 16, K->msm_cmin);
-    env_set("BPG_SWEEP", 0, 2, K->sweep_mode);
-    if (env_present("BPG_SWEEP_PER")) { const long v = env_int_strict("BPG_SWEEP_PER", 2, 16); if (v & (v - 1)) throw std::invalid_argument("BPG_SWEEP_PER: 2, 4, 8 or 16"); K->sweep_per = (uint32_t)v; }
     env_set("BPG_MERGE", 0, 2, K->merge_equal);
     bool resident_set = false;
     if (env_present("BPG_SWEEP_RESIDENT")) { K->sweep_blocks_resident = (uint32_t)env_int_strict("BPG_SWEEP_RESIDENT", 64, 65536); resident_set = true; }
@@ -583,7 +596,7 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (e != hipSuccess || count <= 0) throw DeviceError("no HIP device available: the bpg engine has no CPU path");
     if (device < 0 || device >= count) throw DeviceError("invalid device ordinal");
     HIPCHK(hipSetDevice(device));
-    if (blocking == 1) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
+    if (blocking == 1) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); K->blocking_waits = true; }
     if (!resident_set) {   // blocks of the sweep the device holds at once: 4 per CU of THIS device (a partitioned MI355X shows fewer CUs)
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) K->sweep_blocks_resident = (uint32_t)cus * 4u;
@@ -652,10 +665,10 @@ std::string Engine::profile_report() {
     char sch[896];
     std::snprintf(sch, sizeof sch, "{\"_schedule\": {\"profile\": %u, \"tt_lg\": %u, \"tt_orig_lg\": %u, \"fold_group\": %u, \"fold_wnaf\": %u, \"fold_parts\": %u, "
                   "\"eff_wnaf\": %u, \"eff_parts\": %u, \"fold_adapt\": %u, \"fold_split_max\": %u, \"fold_quad\": %u, \"msm_cmax\": %u, \"msm_cmax_shared\": %u, \"msm_cmin\": %u, "
-                  "\"rseg\": %u, \"lgch\": %u, \"sweep_blocks_resident\": %u, \"shared_variants_last\": %u, \"merge_equal\": %u, \"merged_last\": %u, \"merged_skipped_last\": %u, \"merge_ms_last\": %.3f, \"sweep_mode\": %u, \"sweep_per\": %u, \"table_budget\": %llu, \"table_bytes\": %llu}",
+                  "\"rseg\": %u, \"lgch\": %u, \"sweep_blocks_resident\": %u, \"shared_variants_last\": %u, \"merge_equal\": %u, \"merged_last\": %u, \"merged_skipped_last\": %u, \"merge_ms_last\": %.3f, \"table_budget\": %llu, \"table_bytes\": %llu}",
                   impl_->profile, impl_->tt_lg, impl_->tt_orig_lg, impl_->fold_group, impl_->fold_wnaf, impl_->fold_parts, impl_->eff_wnaf, impl_->eff_parts,
                   impl_->fold_adapt, impl_->fold_split_max, (unsigned)impl_->fold_quad, impl_->msm_cmax, impl_->msm_cmax_shared, impl_->msm_cmin, impl_->rseg, impl_->lgch,
-                  impl_->sweep_blocks_resident, (unsigned)impl_->shared_now, (unsigned)impl_->merge_equal, impl_->merged_last, impl_->merged_skipped_last, impl_->merge_ms_last, impl_->sweep_mode, impl_->sweep_per, (unsigned long long)impl_->table_budget, (unsigned long long)table_bytes_held(device_));
+                  impl_->sweep_blocks_resident, (unsigned)impl_->shared_now, (unsigned)impl_->merge_equal, impl_->merged_last, impl_->merged_skipped_last, impl_->merge_ms_last, (unsigned long long)impl_->table_budget, (unsigned long long)table_bytes_held(device_));
     std::string out = sch;
     bool first = false;
     for (int i = 0; i < KID_COUNT; i++) {
@@ -932,19 +945,14 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     }
     const uint32_t nchunks = cdiv(Mub ? Mub : 1, CH);
     // arena layout of this call: [digits | entries1] overlaid by the sweep's partial sums, then entries
-    const bool sorted_ = sweep_mode == 2 || (sweep_mode == 1 && shared_now);
     const size_t b_digits = al256((size_t)(total ? total : 1) * W * 2), b_e1 = al256((size_t)(live ? live : 1) * W * 4), b_entries = b_e1;
-    const size_t b_slots = al256(sorted_ ? ((size_t)(Mub / BSORT_PART) + (size_t)(Mub / (BSORT_LCAP + 1)) + 1) * sizeof(ge_ext) : (size_t)nchunks * 2 * sizeof(ge_ext));
+    const size_t b_slots = al256((size_t)nchunks * 2 * sizeof(ge_ext));
     const size_t b_front = std::max(b_digits + b_e1, b_slots);
     arena.ensure(b_front + b_entries);
     uint16_t *digits_p = reinterpret_cast<uint16_t *>(arena_at(0));
     uint32_t *entries1_p = reinterpret_cast<uint32_t *>(arena_at(b_digits)), *entries_p = reinterpret_cast<uint32_t *>(arena_at(b_front));
     ge_ext *slots_p = reinterpret_cast<ge_ext *>(arena_at(0));
-    // bucket-major sweep (k_bucket_sorted): a lane per bucket, buckets sorted by length inside a block; buckets of 256 entries and more in parts
-    const bool sorted = sorted_;
-    const uint32_t maxheavy = (uint32_t)(Mub / (BSORT_LCAP + 1)) + 1, maxparts = (uint32_t)(Mub / BSORT_PART) + maxheavy;
-    if (sorted) { heavy.ensure(((size_t)2 * maxheavy + 4) * 4); medium.ensure(((size_t)maxparts + 1) * sizeof(uint2)); }
-    else { heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4); medium.ensure(((size_t)nchunks / 2 + 2) * 4); }      // a bucket on the medium list crosses at least two boundaries
+    heavy.ensure(((size_t)nchunks / HEAVY_CHUNKS + 2) * 4); medium.ensure(((size_t)nchunks / 2 + 2) * 4);      // a bucket on the medium list crosses at least two boundaries
     {
         // (kernels.cuh, "two-level sort"): digits once, coarse partition with coalesced runs, fine counting sort inside each coarse bin
         const uint64_t nflat64 = (uint64_t)nmsm * W * P.CB * P.tmax;
@@ -952,8 +960,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         const uint32_t nflat = (uint32_t)nflat64, nblk1 = cdiv(nflat, SCAN_CHUNK), K = nmsm * W * P.CB;
         counts.ensure((size_t)(nflat + 1) * 4); starts1.ensure((size_t)(nflat + 1) * 4); cursor.ensure((size_t)(nflat + 1) * 4);
         blocksum.ensure((size_t)(nblk1 + 1) * 4);
-        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits_p, heavy.as<uint32_t>(),
-                   sorted ? heavy.as<uint32_t>() + 1 : medium.as<uint32_t>());                     // (zeroes the two list counters of the sweep that follows)
+        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits_p, heavy.as<uint32_t>(), medium.as<uint32_t>());
         HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
         if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits_p, total, counts.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
@@ -962,17 +969,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits_p, total, starts1.as<uint32_t>(), entries1_p);
         BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1_p, starts.as<uint32_t>(), entries_p);
     }
-    if (sorted) {
-        uint2 *partlist = medium.as<uint2>();
-        const uint32_t KB = 256u * sweep_per, nblk = cdiv(nkeys, KB);
-#define BPG_SORTED(PER) BPG_LAUNCH_ID((*this), KID_k_bucket_sorted, k_bucket_sorted<PER>, dim3(nblk), dim3(256), S, starts.as<uint32_t>(), entries_p, buckets.as<ge_ext>(), nkeys, heavy.as<uint32_t>(), partlist)
-        if (sweep_per == 2) BPG_SORTED(2); else if (sweep_per == 4) BPG_SORTED(4); else if (sweep_per == 16) BPG_SORTED(16); else BPG_SORTED(8);
-#undef BPG_SORTED
-        prof_note(KID_k_bucket_sorted, 64.0 * (double)(total - std::min(total, msm_alg_discount)), 100.0 * (double)Mub, 7.0 * (double)Mub);
-        msm_alg_discount = 0;
-        BPG_LAUNCH((*this), k_bucket_heavy_parts, dim3(cdiv(maxparts, 256)), dim3(256), S, starts.as<uint32_t>(), entries_p, heavy.as<uint32_t>(), partlist, slots_p);
-        BPG_LAUNCH((*this), k_bucket_heavy_join, dim3(64), dim3(256), starts.as<uint32_t>(), heavy.as<uint32_t>(), slots_p, buckets.as<ge_ext>());
-    } else {
+    {
         open_keys.ensure((size_t)nchunks * 4);
         ge_ext *slotA = slots_p, *slotB = slotA + nchunks;
         // the true entry count is starts[nkeys] (device side); threads past it exit immediately
@@ -1132,6 +1129,7 @@ void Engine::free_circuit(DeviceCircuit *c) {
 // n = 993,384: a hash-table pass over the scalars, two scans over the table, one point addition per merged-away term and a batched normalisation.
 void Engine::Impl::merge_build(DeviceCircuit::MergeSet &M, const scm *A, const ge_niels *PA, uint32_t nA, const scm *B, const ge_niels *PB, uint32_t nB) {
     const uint32_t nterms = nA + nB;
+    M.groups = 0; M.skipped = 0;
     if (nterms < 2) return;
     MergeTerms T; T.A = A; T.B = B; T.PA = PA; T.PB = PB; T.nA = nA; T.nterms = nterms;
     const uint32_t lgslots = ceil_log2((uint64_t)2 * nterms), slots = 1u << lgslots;        // load <= 1/2
@@ -1169,7 +1167,7 @@ void Engine::Impl::merge_build(DeviceCircuit::MergeSet &M, const scm *A, const g
     BPG_LAUNCH((*this), k_merge_sum, dim3(cdiv(groups, 64)), dim3(64), T, count, moff, goff, gslot, members, groups, scratch_ext.as<ge_ext>(), M.sc.as<scm>());
     BPG_LAUNCH((*this), k_normalize_niels, dim3(cdiv(cdiv(groups, NORM_K), 256)), dim3(256), scratch_ext.as<ge_ext>(), M.pts.as<ge_niels>(), groups);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));
+    if (merge_equal != 2) HIPCHK(hipStreamSynchronize(st));                // (redone in every proof: the sums that follow are queued on the same stream, no wait)
     M.groups = groups; M.skipped = skipped;
 }
 void Engine::Impl::merge_witness(DeviceCircuit *c, const ge_niels *Gtab, const ge_niels *Htab) {
@@ -1191,7 +1189,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                                  const Scalar &w, const ge_niels *Gtab, const ge_niels *Htab, const ge_niels *Bn, ProveTimings *tm, double &t0) {
     Impl &I = *this;
     const uint32_t lgN = ceil_log2(N);
-    auto lap = [&](double *slot) { if (tm) { HIPCHK(hipStreamSynchronize(st)); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
+    auto lap = [&](double *slot) { if (tm) { I.wait_stream(); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
     T.innerproduct_domain_sep(N);
     std::vector<Scalar> yinv_pow2(lgN + 1);
     yinv_pow2[0] = yinv; for (uint32_t k = 1; k <= lgN; k++) yinv_pow2[k] = yinv_pow2[k - 1] * yinv_pow2[k - 1];
@@ -1242,7 +1240,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             uint8_t lr[64];
             uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);       // L, R as extended points; encoded on the host
             HIPCHK(hipMemcpyAsync(hp, I.msm_result.p, 2 * sizeof(ge_ext), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            I.wait_stream();
             h51::pt_compress(lr, h51::pt_from_device(hp)); h51::pt_compress(lr + 32, h51::pt_from_device(hp + 32));
             lap(tm ? &tm->ipa_msm : nullptr);
             T.append_point("L", lr); T.append_point("R", lr + 32);
@@ -1289,7 +1287,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             tk = I.msm(S, 2);
         }
         uint8_t lr[64];
-        HIPCHK(hipStreamSynchronize(st));
+        I.wait_stream();
         { const std::vector<h51::pt> LR = I.msm_points(tk); h51::pt_compress(lr, LR[0]); h51::pt_compress(lr + 32, LR[1]); }
         lap(tm ? &tm->ipa_msm : nullptr);
         T.append_point("L", lr); T.append_point("R", lr + 32);
@@ -1398,7 +1396,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
             }
             BPG_LAUNCH(I, k_normalize_niels, dim3(cdiv(cdiv(2 * Mr, NORM_K), 256)), dim3(256), I.scratch_ext.as<ge_ext>(), dst, 2 * Mr);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipStreamSynchronize(st));                               // h_naf is reused by the next group
+            I.wait_stream();                               // h_naf is reused by the next group
             Gst = dst; Hst = dst + Mr;
             for (const Scalar &uk : g_us) { Gamma = uk.invert() * Gamma; Eta = uk * Eta; }
             g_j = 0; g_index++;
@@ -1409,7 +1407,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
     scm ab[2];
     HIPCHK(hipMemcpyAsync(&ab[0], a, sizeof(scm), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&ab[1], b, sizeof(scm), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    I.wait_stream();
     { uint8_t o[64]; from_scm(ab[0]).to_bytes(o); from_scm(ab[1]).to_bytes(o + 32); proof.insert(proof.end(), o, o + 64); }
 }
 
@@ -1535,7 +1533,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const bool compact = flags & 1u, no_1phase = flags & 2u;
     const double t_begin = now_ms();
     double t0 = t_begin;
-    auto lap = [&](double *slot) { if (tm) { HIPCHK(hipStreamSynchronize(st)); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
+    auto lap = [&](double *slot) { if (tm) { I.wait_stream(); double t1 = now_ms(); *slot += t1 - t0; t0 = t1; } };
 
     const ge_niels *Gtab = I.gens.as<ge_niels>(), *Htab = I.gens.as<ge_niels>() + gens_cap_;
     const ge_niels *Bn = I.bases.as<ge_niels>(), *Bbn = Bn + 1;
@@ -1696,7 +1694,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         HIPCHK(hipGetLastError());
         uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);           // three extended points; encoded on the host
         HIPCHK(hipMemcpyAsync(hp, I.msm_result.p, 3 * sizeof(ge_ext), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        I.wait_stream();
         for (int k = 0; k < 3; k++) h51::pt_compress(pts + 32 * k, h51::pt_from_device(hp + 32 * k));
     } else if (merged) {
         MsmSegs S = seg_new();
@@ -1705,12 +1703,12 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
         seg_push(S, sR, Htab, (uint32_t)n, 2);
         seg_push(S, I.extras.as<scm>() + 2, Bbn, 1, 2);
         const Impl::MsmTicket tk = I.msm(S, 3);
-        HIPCHK(hipStreamSynchronize(st));
+        I.wait_stream();
         const std::vector<h51::pt> P3 = I.msm_points(tk);
         for (int k = 0; k < 3; k++) h51::pt_compress(pts + 32 * k, P3[k]);
     } else {
         launch_pieces(2 * n);
-        HIPCHK(hipStreamSynchronize(st));
+        I.wait_stream();
         const std::vector<h51::pt> AB = I.msm_points(tk_aiao);
         h51::pt Sp = I.msm_points(tk_s[0])[0];
         for (uint32_t k = 1; k < nparts; k++) Sp = h51::pt_add(Sp, I.msm_points(tk_s[k])[0]);
@@ -1760,7 +1758,7 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     if (m) HIPCHK(hipMemcpyAsync(h_wV.data(), wV, m * sizeof(scm), hipMemcpyDeviceToHost, st));
     uint32_t *h_stale = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 32768);
     HIPCHK(hipMemcpyAsync(h_stale, I.stale_flag.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    I.wait_stream();
     if (*h_stale) {   // a blinding draw was read from a slab position no upload of this proof wrote (k_sc_from_wide): nothing of this proof may leave
         HIPCHK(hipMemsetAsync(I.stale_flag.p, 0, 4, st));
         throw DeviceError("a blinding draw was read before it was uploaded (stale device slab): proof withheld");

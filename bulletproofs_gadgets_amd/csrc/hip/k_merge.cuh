@@ -12,7 +12,9 @@ namespace bpg {
 // about 35,000 distinct scalars.  Nothing here knows about gadgets: the terms are grouped by VALUE with a hash table.
 //   k_merge_insert   term t (scalar A[t] on PA[t] for t < nA, B[t-nA] on PB[t-nA] beyond), non-zero: finds / claims the slot of its value (open
 //                    addressing, atomicCAS on the slot's representative term, full 32-byte compare on a hit), counts the slot's members
-//   k_merge_plan     a slot with c >= 2 members becomes ceil(c / MERGE_GMAX) groups (a group is summed by one thread) and takes c member places
+//   k_merge_plan     a slot with c >= 2 members becomes ceil(c / MERGE_GMAX) groups (a group is summed by one thread: at most 32 additions in a row, so that
+//                    the grouping costs a proof a fraction of a millisecond even when it is redone for every proof; the groups of one value are
+//                    separate terms with the same scalar, which the sweep adds up in their common buckets) and takes c member places
 //   (two scans)      member places and group numbers of every slot
 //   k_merge_groups   the slot of every group
 //   k_merge_members  members enter their slot's list and set their bit in the skip masks (MsmSegs::skip: no entry in any window)
@@ -21,7 +23,7 @@ namespace bpg {
 // Done once per uploaded witness (Engine::Impl::merge_witness), not per proof: the grouping depends on the witness alone.  The order in which members
 // arrive in a list depends on the schedule, so the projective sums differ from run to run; the normalised points are the same group elements.
 #define MERGE_EMPTY 0xffffffffu
-#define MERGE_GMAX 1024u
+#define MERGE_GMAX 32u
 struct MergeTerms { const scm *A, *B; const ge_niels *PA, *PB; uint32_t nA, nterms; };
 __device__ __forceinline__ const scm &merge_scalar(const MergeTerms &T, uint32_t t) { return t < T.nA ? T.A[t] : T.B[t - T.nA]; }
 __device__ __forceinline__ uint32_t merge_hash(const scm &s) {
@@ -45,7 +47,8 @@ __global__ void __launch_bounds__(256) k_merge_insert(MergeTerms T, uint32_t *__
     const uint32_t mask = (1u << lgslots) - 1u;
     uint32_t slot = merge_hash(s) & mask;
     for (;;) {                                                            // load <= 1/2: terminates
-        const uint32_t cur = atomicCAS(&rep[slot], MERGE_EMPTY, t);
+        uint32_t cur = __hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // hundreds of terms may carry this value: only the first few race for the slot
+        if (cur == MERGE_EMPTY) cur = atomicCAS(&rep[slot], MERGE_EMPTY, t);
         if (cur == MERGE_EMPTY) break;                                    // claimed
         if (merge_equal(merge_scalar(T, cur), s)) break;                  // a slot only ever holds terms of one value, so any representative will do
         slot = (slot + 1u) & mask;

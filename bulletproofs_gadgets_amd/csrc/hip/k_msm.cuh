@@ -427,128 +427,6 @@ __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__
     }
 }
 
-// ------------------------------------------------------------------------------------------------ bucket-major sweep (round 5)
-// The balanced sweep above cuts the sorted entry list into equal chunks, so every lane pays, entry after entry, for the possibility that its chunk
-// crosses a bucket boundary (with ~32 entries per bucket and 64 lanes a wave takes the boundary branch - stores, a reset of the accumulator, the next
-// bucket's limits - in six iterations out of seven), and the pieces of a bucket have to be joined afterwards (k_bucket_combine, its heavy list, 256 bytes
-// of partial sums per chunk).  Bucket lengths in a window are Poisson around total / 2^(c-1); what a lane-per-bucket sweep loses is only the SPREAD of
-// the lengths inside a wave.  So: a block takes KB = 256 * PER consecutive buckets, sorts them by length in LDS (a counting sort: lengths are below 256
-// here), and each wave sweeps 64 buckets of (nearly) equal length, one per lane, longest first - no boundary inside the loop, the bucket sum goes straight
-// to buckets[key], nothing to join.  2,048 buckets per block keep 98 % of the lane-iterations busy at 32 entries per bucket (98.6 % at 61).  Buckets of
-// 256 entries and more (thousands of identical scalars: range-proof bits, repeated witness values) are cut into parts of BSORT_PART entries for
-// k_bucket_heavy_parts (a LANE per part: the same loop, every lane 64 entries long) and k_bucket_heavy_join (a wave per bucket sums its parts).
-#define BSORT_LCAP 255u
-#define BSORT_PART 64u
-template <int PER> __global__ void __launch_bounds__(256) k_bucket_sorted(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
-                                                                           ge_ext *__restrict__ buckets, uint32_t nkeys,
-                                                                           uint32_t *__restrict__ heavy /* [0] buckets, [1] parts, then (key, first part) pairs */,
-                                                                           uint2 *__restrict__ partlist /* (key, part) per heavy part */) {
-    constexpr uint32_t KB = 256u * PER;
-    __shared__ uint32_t hist[256], base[256], wtot[4];
-    __shared__ uint32_t s_start[KB];
-    __shared__ uint16_t s_key[KB];
-    __shared__ uint8_t s_len[KB];
-    const uint32_t k0 = blockIdx.x * KB, kb = k0 + threadIdx.x * PER, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t st[PER + 1], slot[PER];
-#pragma unroll
-    for (int j = 0; j <= PER; j++) st[j] = starts[min(kb + (uint32_t)j, nkeys)];
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const uint32_t len = st[j + 1] - st[j];
-        slot[j] = 0;
-        if (len > BSORT_LCAP) {                                            // (keys past nkeys have len 0)
-            const uint32_t np = (len + BSORT_PART - 1u) / BSORT_PART;
-            const uint32_t h = atomicAdd(&heavy[0], 1u), p0 = atomicAdd(&heavy[1], np);
-            heavy[2 + 2 * h] = kb + j; heavy[3 + 2 * h] = p0;
-            for (uint32_t p = 0; p < np; p++) partlist[p0 + p] = make_uint2(kb + j, p);
-        } else if (len) slot[j] = atomicAdd(&hist[len], 1u);
-    }
-    __syncthreads();
-    {   // base[L] = buckets of this block that are LONGER than L: longest first.  A suffix scan over the 256 counters: waves by shuffles, then the wave totals
-        const uint32_t v = hist[threadIdx.x];
-        uint32_t incl = v;
-#pragma unroll
-        for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_down(incl, d, 64); if (lane + d < 64) incl += o; }
-        if (lane == 0) wtot[wv] = incl;
-        __syncthreads();
-        uint32_t off = 0;
-        for (uint32_t k = wv + 1; k < 4; k++) off += wtot[k];
-        base[threadIdx.x] = off + incl - v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        const uint32_t len = st[j + 1] - st[j];
-        if (len && len <= BSORT_LCAP) {
-            const uint32_t pos = base[len] + slot[j];
-            s_start[pos] = st[j]; s_key[pos] = (uint16_t)(threadIdx.x * PER + j); s_len[pos] = (uint8_t)len;
-        }
-    }
-    __syncthreads();
-    const uint32_t nn = base[0], groups = (nn + 63u) >> 6;                 // (hist[0] stays 0: base[0] counts every bucket swept here)
-    // groups are dealt to the four waves boustrophedon (0 1 2 3 | 3 2 1 0 | ...): the lengths fall from group to group, so each wave gets the same total
-    for (uint32_t r = 0; 4u * r < groups; r++) {
-        const uint32_t g = 4u * r + ((r & 1u) ? 3u - wv : wv);
-        if (g >= groups) continue;
-        const uint32_t idx = g * 64u + lane;
-        const bool valid = idx < nn;
-        const uint32_t len = valid ? s_len[idx] : 0u, e0 = valid ? s_start[idx] : 0u;
-        const uint32_t lmax = __builtin_amdgcn_readfirstlane(len);        // lane 0 holds the longest bucket of the group
-        uint32_t ent = len ? entries[e0] : 0u;
-        ge_ext acc = ge_identity();
-        for (uint32_t i = 0; i < lmax; i++) {
-            if (i < len) {
-                const uint32_t sg = (ent >> 27) & 15u, neg = ent >> 31;
-                const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
-                const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];
-                if (i + 1 < len) ent = entries[e0 + i + 1];
-                acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
-            }
-        }
-        if (valid) buckets[k0 + s_key[idx]] = acc;
-    }
-}
-// a lane per part of a heavy bucket (BSORT_PART entries, the last part of a bucket fewer): the loop of k_bucket_sorted without its prologue
-__global__ void __launch_bounds__(256) k_bucket_heavy_parts(MsmSegs S, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ entries,
-                                                            const uint32_t *__restrict__ heavy, const uint2 *__restrict__ partlist, ge_ext *__restrict__ hparts) {
-    const uint32_t gp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gp >= heavy[1]) return;
-    const uint2 kp = partlist[gp];
-    const uint32_t e0 = starts[kp.x] + kp.y * BSORT_PART, e1 = min(e0 + BSORT_PART, starts[kp.x + 1]);
-    uint32_t ent = entries[e0];
-    ge_ext acc = ge_identity();
-    for (uint32_t e = e0; e < e1; e++) {
-        const uint32_t sg = (ent >> 27) & 15u, neg = ent >> 31;
-        const fe *q = reinterpret_cast<const fe *>(S.pts[sg] + msm_point_index(S, sg, ent & 0x07ffffffu));
-        const fe qp = q[neg], qm = q[neg ^ 1u], t2d = q[2];
-        if (e + 1 < e1) ent = entries[e + 1];
-        acc = ge_madd_swapped(acc, qp, qm, t2d, neg);
-    }
-    hparts[gp] = acc;
-}
-// a wave per heavy bucket: its parts summed lane-strided, then a tree over the wave through LDS
-__global__ void __launch_bounds__(256) k_bucket_heavy_join(const uint32_t *__restrict__ starts, const uint32_t *__restrict__ heavy, const ge_ext *__restrict__ hparts,
-                                                           ge_ext *__restrict__ buckets) {
-    __shared__ ge_ext lds[256];
-    const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    ge_ext *L = lds + wv * 64;
-    for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {       // wave-uniform trip count; no block barrier inside
-        const uint32_t k = heavy[2 + 2 * it], p0 = heavy[3 + 2 * it];
-        const uint32_t np = (starts[k + 1] - starts[k] + BSORT_PART - 1u) / BSORT_PART;
-        ge_ext acc = ge_identity();
-        for (uint32_t p = lane; p < np; p += 64) acc = ge_add(acc, hparts[p0 + p]);
-        L[lane] = acc;
-        for (uint32_t d = 32; d > 0; d >>= 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < d) L[lane] = ge_add(L[lane], L[lane + d]);
-        }
-        if (lane == 0) buckets[k] = L[0];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-}
-
 // Epilogue of a window: S = sum_b (b+1) * bucket[b] over its nb buckets, in two levels of running sums and one weighted tree - no scalar
 // multiplication by a bucket index anywhere (rounds 1-3 added lo * run per segment by double-and-add: 15 doublings + ~7 additions for every 8
 // buckets, more field multiplications than the running sums themselves and a third of the instructions of the sweep it follows).

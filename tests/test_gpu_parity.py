@@ -220,8 +220,8 @@ def test_msm_epilogue_and_sweep_knobs_give_the_oracle_sum(env, monkeypatch):
 def test_equal_scalar_merging_changes_no_byte(merge, monkeypatch):
     """Terms of A_I that carry the same scalar share one bucket entry per window on the sum of their generators (hip/k_merge.cuh; a MiMC round wires
     a_L[2i] = a_R[2i] = a_R[2i+1], reference src/mimc_hash/mimc_hash_gadget.rs:133-144): grouped by value once per uploaded witness.  With the merging
-    on and off (BPG_MERGE), on circuits with groups of two, three, eight, nine, forty and hundreds of members (range-proof bits; groups beyond 1,024
-    members are summed in parts) and with zero scalars (never grouped), the proof is the oracle's, byte for byte.  BPG_TT_LG=0 sends these small circuits down the
+    on and off (BPG_MERGE), on circuits with groups of two, three, eight, nine, forty and hundreds of members (range-proof bits; a value class beyond 32
+    members becomes several groups) and with zero scalars (never grouped), the proof is the oracle's, byte for byte.  BPG_TT_LG=0 sends these small circuits down the
     bucket-method path that the full-size ones take."""
     monkeypatch.setenv("BPG_MERGE", merge)
     monkeypatch.setenv("BPG_TT_LG", "0")
@@ -250,7 +250,7 @@ def test_equal_scalar_merging_changes_no_byte(merge, monkeypatch):
         p.constrain(bpg.LinearCombination.of(l) - r)                               # (one constraint, satisfied: left = right)
         check_against_oracle(c, p, t, [], 128)
         if merge != "0":
-            assert c.schedule()["merged_last"] == 6                                # the five value classes of a_L and the (x, x) pair; a_O = x y: all different
+            assert c.schedule()["merged_last"] == 7                                # the five value classes of a_L (the one of 40 members as two groups) and the (x, x) pair; a_O = x y: all different
     finally:
         c.close()
 

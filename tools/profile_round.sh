@@ -14,9 +14,12 @@
 #          (tools/diag/mask_build.sh must have built tools/diag/libbpg_hip_mask.so in the build container) -> <tag>_mask_ab.txt
 #   clock  shader clock and board power while the mix / one stream runs (tools/diag/clock_watch.py) -> <tag>_clock.txt
 #   appetite  value / HBM / busy cores for {serving, one-shot} x {20, 10, 6} streams (tools/diag/appetite.sh) -> <tag>_appetite.txt
+#   inv    what a field inversion and a mixed addition cost in field multiplications (tools/diag/bench_inv.hip): the constants behind "no batched-affine sweep" -> <tag>_inversion_cost.json
+# The sanitizer evidence (profiles/<tag>_sanitizers.txt) is taken in the BUILD container, last, by tools/sanitize_round.sh <tag>, which fails when its source
+# hash differs from the one in the counter files this script wrote.
 # rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
 set -o pipefail
-tag=${1:-r04}; shift
+tag=${1:-r05}; shift
 stages=${*:-calib stats pmc bench}
 root=$(pwd)
 out=$root/gpurun_out
@@ -34,6 +37,11 @@ if has calib; then
     (cd /tmp && timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/${tag}_calib_pmc" -o "$tag" -- /tmp/gather_calib > /dev/null 2> "$out/${tag}_calib_pmc.err") || { echo "calib pmc pass failed"; tail -5 "$out/${tag}_calib_pmc.err"; exit 1; }
     python3 "$root/tools/calib/fetch_factor.py" "$out/${tag}_calib_known.json" "$(csv "$out/${tag}_calib_pmc" counter_collection.csv)" "$out/${tag}_fetch_calibration.json" || exit 1
     echo "calib done"
+fi
+if has inv; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-pass-failed -o /tmp/bench_inv "$root/tools/diag/bench_inv.hip" || { echo "bench_inv build failed"; exit 1; }
+    (cd /tmp && timeout -k 10 120 /tmp/bench_inv > "$out/${tag}_inversion_cost.json") || { echo "bench_inv run failed"; exit 1; }
+    echo "inv done"
 fi
 if has stats; then
     (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/${tag}_stats" -o "$tag" -- python3 "$root/bench.py" --headline-only --steps 20 --warmup 5 > "$out/${tag}_bench_under_rocprof.json" 2> "$out/${tag}_stats.err") || { echo "stats pass failed"; tail -5 "$out/${tag}_stats.err"; exit 1; }
