@@ -558,7 +558,7 @@ def end_to_end(bpg, workloads, ctx, capacity, expect, seed):
 # ------------------------------------------------------------------------------------------------ one rank
 def one_shot_leg(args):
     """`value_one_shot`: the SAME K timed steps (same command, streams, chain pool, seeds) with every context under the ONE-SHOT profile - what a
-    drop-in caller of bpg_ctx_create(device) gets: first fold on width-6 NAF tables of whole scalars (3.0 GB at 2^20), no 8-bit tail tables.  Run as
+    drop-in caller of bpg_ctx_create(device) gets: first fold on width-5 NAF tables of scalars cut in two (3.0 GB at 2^20), no 8-bit tail tables.  Run as
     a child process: tables are per process and device, and the serving tables this process holds would count against the one-shot budget."""
     cmd = [sys.executable, str(ROOT / "bench.py"), "--headline-only", "--profile", "oneshot", "--no-one-shot-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--leaves", str(args.leaves), "--streams", str(args.streams), "--chain-workers", str(args.chain_workers), "--chain-lanes", str(args.chain_lanes),

@@ -371,8 +371,8 @@ struct Engine::Impl {
     // odd multiples (2m+1) * 2^(j*L) * P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf, scalars
     // cut into `fold_parts` pieces of L bits); built on first use for the device's generator tables and shared with them
     DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
-    uint32_t fold_wnaf = 6;          // width of the NAF the first fold recodes its scalars in (BPG_FOLD_WNAF; one-shot profile 6, serving 8; 0 = register kernels)
-    uint32_t fold_parts = 1;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2, 4 or 8; serving 4)
+    uint32_t fold_wnaf = 5;          // width of the NAF the first fold recodes its scalars in (BPG_FOLD_WNAF; one-shot profile 5, serving 8; 0 = register kernels)
+    uint32_t fold_parts = 2;         // the scalars of the first fold are cut into this many parts on tables of 2^(j*L) * P (BPG_FOLD_PARTS: 1, 2, 4 or 8; one-shot 2, serving 4)
     uint64_t fold_table_budget = 64ull << 30;       // per-kind cap of the fold tables (BPG_FOLD_TABLE_GB); the cumulative bound is table_budget
     uint32_t eff_wnaf = 0, eff_parts = 0;            // what odd_ensure settled on for the current capacity
     uint32_t fold_part_bits() const { return (254 + eff_parts - 1) / eff_parts; }
@@ -553,10 +553,11 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     if (blocking < 0 && env_present("BPG_SYNC_BLOCKING")) blocking = env_int_strict("BPG_SYNC_BLOCKING", 0, 1) ? 1 : 0;
     uint32_t profile = cfg.profile;
     if (profile == 0) { if (const char *e = std::getenv("BPG_PROFILE")) profile = (!std::strcmp(e, "serving") || !std::strcmp(e, "2")) ? 2u : 1u; else profile = 1u; }
-    // one-shot (the default of a bare bpg_ctx_create): width-6 NAF fold tables on whole scalars (3.0 GB at 2^20, built in 7 ms), no 8-bit tail
-    // tables, 4 GB of tables in all; serving: width-8 NAF on scalars cut in four (51.5 GB at 2^20, 0.12 s), 8-bit tail tables (17.2 GB at 2^14), 96 GB
+    // one-shot (the default of a bare bpg_ctx_create): width-5 NAF fold tables on scalars cut in two (15 tables, 3.0 GB at 2^20; round 5: the same bytes as the
+    // width-6 tables of whole scalars it replaces, 127 doublings instead of 253 for 42 instead of 36 additions per scalar: the first fold 5.6 -> 5.0 ms), no 8-bit
+    // tail tables, 4 GB of tables in all; serving: width-8 NAF on scalars cut in four (51.5 GB at 2^20, 0.12 s), 8-bit tail tables (17.2 GB at 2^14), 96 GB
     if (profile == 2) { K->fold_wnaf = 8; K->fold_parts = 4; K->tt_wide_budget = 24ull << 30; K->table_budget = 96ull << 30; }
-    else { K->fold_wnaf = 6; K->fold_parts = 1; K->tt_wide_budget = 0; K->table_budget = 4ull << 30; }
+    else { K->fold_wnaf = 5; K->fold_parts = 2; K->tt_wide_budget = 0; K->table_budget = 4ull << 30; }
     K->profile = profile;
     {
         double gb = cfg.table_budget_gb;

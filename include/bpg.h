@@ -91,7 +91,7 @@ const char *bpg_last_error(void);                                /* message of t
  * bpg_ctx_create_ex takes the choices a host has: a zeroed bpg_config with struct_size set means "defaults"; a field left at 0 / NULL falls
  * back to the environment variable named beside it, then to the profile's default.  Every setting gives the same proof bytes. */
 #define BPG_PROFILE_DEFAULT 0u   /* BPG_PROFILE=oneshot|serving if set, else one-shot */
-#define BPG_PROFILE_ONESHOT 1u   /* first generator fold on width-6 NAF tables of whole scalars; no 8-bit tail tables; table budget 4 GB */
+#define BPG_PROFILE_ONESHOT 1u   /* first generator fold on width-5 NAF tables of scalars cut in two (15 tables: 3.0 GB at 2^20); no 8-bit tail tables; table budget 4 GB */
 #define BPG_PROFILE_SERVING 2u   /* a long-lived prover: width-8 NAF on scalars cut in four (51.5 GB of tables at 2^20, built once per device in 0.12 s,
                                     shared by the contexts of the process: -2.4 ms per 2^20 proof), 8-bit tail tables for circuits up to 2^14
                                     multipliers (17.2 GB); table budget 96 GB */
