@@ -1173,7 +1173,7 @@ def run_rank(args):
                                       "grouped once per uploaded witness, outside the timed steps - `throughput_variants.merge_per_proof` has it inside every proof"}
             out["throughput"] = thr
             try:
-                out["throughput_variants"] = throughput_variants(bpg, workloads, device_index, inst, state, a.gens_capacity, args.in_flight, max(2, args.in_flight_steps // 2),
+                out["throughput_variants"] = throughput_variants(bpg, workloads, device_index, inst, state, a.gens_capacity, args.in_flight, max(2, args.in_flight_steps),
                                                                  max(1, args.in_flight_workers), max(1, min(8, args.in_flight_lanes)), args.leaves)
             except Exception as e:      # noqa: BLE001
                 out["throughput_variants"] = {"error": repr(e)}
