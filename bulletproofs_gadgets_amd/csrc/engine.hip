@@ -4,6 +4,7 @@
 // 32..96-byte device->host copy followed by a few hundred bytes host->device.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cerrno>
 #include <cstdio>
@@ -207,8 +208,8 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_blind_poison) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_count1) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) X(k_scan_top) \
-    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_fold_points_quadw) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) \
+    X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_window_sums_quad) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr) X(k_merge_insert) X(k_merge_plan) X(k_merge_groups) X(k_merge_members) X(k_merge_sum)
 enum KernelId {
 #define X(n) KID_##n,
@@ -275,7 +276,7 @@ struct Engine::Impl {
     }
     static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
     // MSM workspace
-    DevBuf counts, starts, cursor, blocksum, buckets, partial, msm_result, open_keys, medium, wsums, tile_hist, heavy, plain, starts1;   // tile_hist, plain: workspace of upload(); digits, the entry lists and the sweep's partial sums live in the arena
+    DevBuf counts, starts, cursor, blocksum, buckets, partial, msm_result, open_keys, medium, wsums, wq_stage, wq_tickets, tile_hist, heavy, plain, starts1;   // tile_hist, plain: workspace of upload(); digits, the entry lists and the sweep's partial sums live in the arena
     uint32_t sweep_blocks_resident = 1024;   // blocks of k_bucket_chunks the device holds at once: 4 per CU of the device the context is created on (BPG_SWEEP_RESIDENT overrides)
     uint32_t msm_cmax = 15;         // widest window of a proof ALONE on the device (BPG_MSM_CMAX sets both caps)
     uint32_t msm_cmax_shared = 16;  // ... and while other proofs share the device: 16 windows instead of 17 per term, twice the buckets (digits are 16-bit)
@@ -296,7 +297,7 @@ struct Engine::Impl {
     // prove buffers
     DevBuf sLR, yinvpow, lv, rv, red_partial, red_out, raw_rng, extras;      // (y^i, z^j and the flattened weights: in the arena)
     DevBuf stale_flag;              // one word, zero unless k_sc_from_wide met a poisoned (never uploaded) draw: checked before a proof leaves prove()
-    DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
+    DevBuf ipa_s, ipa_tabA, ipa_tabB, naf, qsteps, vfy_in, vfy_pts, vfy_ok, vfy_sc, vfy_ch;
     // table-driven IPA tail (kernels.cuh k_tt_*): frozen-generator window tables, per-point factors, coefficient tables
     DevBuf tt_bases, tt_table, tt_f, tt_c, tt_partial, grp_c, ped_table, s_parts;
     // tt_table holds the tables of the ORIGINAL generators G[0..M0), H[0..M0) when tt_orig_M0 != 0: they survive across proofs (a circuit
@@ -367,7 +368,7 @@ struct Engine::Impl {
         shared->wide[M0] = table;                                               // (its bytes were reserved above)
         return table.as<ge_pniels>();
     }
-    PinBuf h_naf;
+    PinBuf h_naf, h_qsteps;
     // odd multiples (2m+1) * 2^(j*L) * P of the original generators for the width-w NAF fold of the first group (k_fold_points_wnaf, scalars
     // cut into `fold_parts` pieces of L bits); built on first use for the device's generator tables and shared with them
     DevBuf gens_odd;                 // view of shared->odd[fold_wnaf | fold_parts << 8] (not owned)
@@ -431,6 +432,9 @@ struct Engine::Impl {
     uint32_t fold_adapt = 1;        // a proof that shares the device with others takes the register fold kernels throughout and sweeps in chunks of 64 (BPG_FOLD_ADAPT: 0 never, 1 when shared, 2 always)
     bool shared_variants() const { return fold_adapt == 2 || (fold_adapt == 1 && device_shared(shared->device)); }
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
+    bool fold_quad_w = true;        // ... with width-4 NAF against multiples the quads make themselves, in the groups after the first (BPG_FOLD_QUAD_W=0: plain NAF, addends in registers)
+    bool window_quad = true;        // window sums of a proof alone: four lanes per point, several blocks per window (BPG_WINDOW_QUAD=0: k_window_sums always)
+    uint32_t window_quad_blocks = 288;   // ... at most this many blocks of four waves per launch (about one wave per SIMD on 256 CUs; BPG_WINDOW_QUAD_BLOCKS)
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
     uint32_t tt_lg = 12;            // freeze the FOLDED generators once a round is down to 2^tt_lg per side: their window tables are built per proof (BPG_TT_LG; 0 = never)
     uint32_t tt_orig_lg = 14;       // a circuit of N <= 2^tt_orig_lg freezes the ORIGINAL generators at round 0: those tables are built once and also serve A_I, A_O, S
@@ -582,6 +586,9 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     env_set("BPG_LGCH", 2, 10, K->lgch);
     env_set("BPG_FOLD_SPLIT", 0, 1 << 24, K->fold_split_max);
     if (env_present("BPG_FOLD_QUAD")) K->fold_quad = env_int_strict("BPG_FOLD_QUAD", 0, 1) != 0;
+    if (env_present("BPG_FOLD_QUAD_W")) K->fold_quad_w = env_int_strict("BPG_FOLD_QUAD_W", 0, 1) != 0;
+    if (env_present("BPG_WINDOW_QUAD")) K->window_quad = env_int_strict("BPG_WINDOW_QUAD", 0, 1) != 0;
+    env_set("BPG_WINDOW_QUAD_BLOCKS", 1, 65536, K->window_quad_blocks);
     env_set("BPG_FOLD_ADAPT", 0, 2, K->fold_adapt);
     env_set("BPG_FOLD_GROUP", 1, 5, K->fold_group);
     if (env_present("BPG_TT_WIDE_GB")) K->tt_wide_budget = (uint64_t)(env_double_strict("BPG_TT_WIDE_GB", 0.0, 4096.0) * (double)(1ull << 30));
@@ -641,11 +648,11 @@ Engine::~Engine() {
     DevBuf *bufs[] = {&impl_->bases, &impl_->scratch_ext, &impl_->comp, &impl_->small_in, &impl_->small_sc, &impl_->counts,
                       &impl_->starts, &impl_->cursor, &impl_->blocksum, &impl_->arena, &impl_->buckets, &impl_->partial, &impl_->msm_result,
                       &impl_->sLR, &impl_->yinvpow, &impl_->lv, &impl_->rv, &impl_->red_partial,
-                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->wsums, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
+                      &impl_->red_out, &impl_->raw_rng, &impl_->extras, &impl_->ipa_s, &impl_->ipa_tabA, &impl_->ipa_tabB, &impl_->naf, &impl_->qsteps, &impl_->wsums, &impl_->wq_stage, &impl_->wq_tickets, &impl_->vfy_in, &impl_->vfy_pts, &impl_->vfy_ok, &impl_->vfy_sc, &impl_->vfy_ch,
                       &impl_->stale_flag, &impl_->tile_hist, &impl_->heavy, &impl_->plain, &impl_->open_keys, &impl_->medium, &impl_->tt_bases, &impl_->tt_table, &impl_->tt_f, &impl_->tt_c, &impl_->tt_partial, &impl_->grp_c, &impl_->ped_table, &impl_->s_parts, &impl_->starts1};
     for (DevBuf *b : bufs) b->release();
     impl_->shared.reset();                                   // the generator tables go with their last context
-    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
+    impl_->h_raw.release(); impl_->h_small.release(); impl_->h_naf.release(); impl_->h_qsteps.release(); impl_->stage.release(); for (PinBuf &b : impl_->h_blind) b.release();
     for (auto &sd : impl_->slab_dev) {
         if (sd->copy_st) { (void)hipStreamSynchronize(sd->copy_st); (void)hipStreamDestroy(sd->copy_st); }
         for (hipEvent_t e : sd->ev) (void)hipEventDestroy(e);
@@ -961,11 +968,10 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         const uint32_t nflat = (uint32_t)nflat64, nblk1 = cdiv(nflat, SCAN_CHUNK), K = nmsm * W * P.CB;
         counts.ensure((size_t)(nflat + 1) * 4); starts1.ensure((size_t)(nflat + 1) * 4); cursor.ensure((size_t)(nflat + 1) * 4);
         blocksum.ensure((size_t)(nblk1 + 1) * 4);
-        BPG_LAUNCH((*this), k_msm_digits, dim3(cdiv(total ? total : 1, 256)), dim3(256), S, P, total, digits_p, heavy.as<uint32_t>(), medium.as<uint32_t>());
         HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
-        if (ntiles) BPG_LAUNCH((*this), k_msm_count1, dim3(ntiles, W), dim3(256), P, digits_p, total, counts.as<uint32_t>());
+        if ((size_t)W * P.CB * 4 > 64 * 1024) throw std::logic_error("msm: coarse histograms exceed the LDS of a block");
+        BPG_LAUNCH_LDS((*this), KID_k_msm_digits, k_msm_digits, dim3(ntiles ? ntiles : 1), dim3(1024), (size_t)W * P.CB * 4, S, P, total, digits_p, counts.as<uint32_t>(), heavy.as<uint32_t>(), medium.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
-        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk1);
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
         if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits_p, total, starts1.as<uint32_t>(), entries1_p);
         BPG_LAUNCH((*this), k_msm_sort2, dim3(K), dim3(256), P, starts1.as<uint32_t>(), nflat, entries1_p, starts.as<uint32_t>(), entries_p);
@@ -994,8 +1000,23 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
     BPG_LAUNCH((*this), k_bucket_reduce, dim3(cdiv(nred, 64)), dim3(64), buckets.as<ge_ext>(), starts.as<uint32_t>(), partial.as<ge_ext>(), nb, seg, nsegpw, nred);
     wsums.ensure((size_t)nmsm * W * sizeof(ge_ext));
     // a window's block: as many threads as it has segments, at most 512 for a proof alone (shortest chain) and 256 while the device is shared (fewest additions)
+    if (!shared_now && window_quad) {
+        // a proof alone: four lanes per point, a window spread over nblk blocks of 64 slots so that the launch is about one wave per SIMD (k_msm.cuh k_window_sums_quad);
+        // per = segments per slot, nblk = blocks per window (at most 64: one slot each in the last block's second stage)
+        const uint32_t nwin = nmsm * W;
+        uint32_t lgper = 0;
+        auto nblk_of = [&](uint32_t lp) { return std::max<uint32_t>(1u, nsegpw >> (6 + lp)); };
+        while (nblk_of(lgper) > 1 && ((uint64_t)nwin * nblk_of(lgper) > window_quad_blocks || nblk_of(lgper) > 64)) lgper++;
+        const uint32_t nblk = nblk_of(lgper);
+        wq_stage.ensure((size_t)nwin * nblk * 2 * sizeof(ge_ext));
+        if (!wq_tickets.p) { wq_tickets.ensure(1024 * 4); HIPCHK(hipMemsetAsync(wq_tickets.p, 0, 1024 * 4, st)); }
+        if (nwin > 1024) throw std::logic_error("msm: too many windows for the ticket array");
+        BPG_LAUNCH((*this), k_window_sums_quad, dim3(nblk, nwin), dim3(256), partial.as<ge_ext>(), wsums.as<ge_ext>(), wq_stage.as<ge_ext>(), wq_tickets.as<uint32_t>(), nsegpw, nred,
+                   ceil_log2(seg), lgper);
+    } else {
     const uint32_t wthreads = std::max<uint32_t>(64, std::min<uint32_t>(nsegpw, shared_now ? 256u : 512u));
     BPG_LAUNCH((*this), k_window_sums, dim3(nmsm * W), dim3(wthreads), partial.as<ge_ext>(), wsums.as<ge_ext>(), nsegpw, nred, ceil_log2(seg));
+    }
     HIPCHK(hipGetLastError());
     if ((size_t)nmsm * W * sizeof(ge_ext) > WS_SLOT_BYTES) throw std::logic_error("msm: window sums exceed the host slot");
     h_wsums.ensure((size_t)WS_SLOTS * WS_SLOT_BYTES);
@@ -1084,10 +1105,8 @@ DeviceCircuit *Engine::upload(const FlatView &c) {
             if (q) BPG_LAUNCH(I, k_csc_count, dim3(cdiv(q, 256)), dim3(256), rp, tv, (uint32_t)q, (uint32_t)n, (uint32_t)m, I.counts.as<uint32_t>(), rowconst);
             // exclusive scans: variable columns -> starts / cursor, constant terms per row -> rowconst_start
             BPG_LAUNCH(I, k_scan_blocksums, dim3(nb1), dim3(256), I.counts.as<uint32_t>(), (uint32_t)nvar, I.blocksum.as<uint32_t>());
-            BPG_LAUNCH(I, k_scan_top, dim3(1), dim3(64), I.blocksum.as<uint32_t>(), nb1);
             BPG_LAUNCH(I, k_scan_apply, dim3(nb1), dim3(256), I.counts.as<uint32_t>(), (uint32_t)nvar, I.blocksum.as<uint32_t>(), I.starts.as<uint32_t>(), I.cursor.as<uint32_t>());
             BPG_LAUNCH(I, k_scan_blocksums, dim3(nb2), dim3(256), rowconst, (uint32_t)q, I.blocksum.as<uint32_t>());
-            BPG_LAUNCH(I, k_scan_top, dim3(1), dim3(64), I.blocksum.as<uint32_t>(), nb2);
             BPG_LAUNCH(I, k_scan_apply, dim3(nb2), dim3(256), rowconst, (uint32_t)q, I.blocksum.as<uint32_t>(), rowconst_start, I.counts.as<uint32_t>() /* scratch */);
             I.extras.ensure(16 * sizeof(scm));
             uint32_t *totals = reinterpret_cast<uint32_t *>(I.extras.as<scm>() + 8);
@@ -1149,7 +1168,6 @@ void Engine::Impl::merge_build(DeviceCircuit::MergeSet &M, const scm *A, const g
     BPG_LAUNCH((*this), k_merge_plan, dim3(cdiv(slots, 256)), dim3(256), count, msize, gcount, slots);
     auto scan = [&](uint32_t *in, uint32_t *out) {        // exclusive scan of in[0..slots) -> out[0..slots], out[slots] = total; `fill` is the scan's scratch cursor
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk), dim3(256), in, slots, blocksum.as<uint32_t>());
-        BPG_LAUNCH((*this), k_scan_top, dim3(1), dim3(64), blocksum.as<uint32_t>(), nblk);
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk), dim3(256), in, slots, blocksum.as<uint32_t>(), out, fill);
     };
     scan(msize, moff); scan(gcount, goff);
@@ -1376,7 +1394,42 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
                 const bool regs = nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15;
                 const uint32_t split_max = (regs && I.shared_now) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
-                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad) {
+                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad && I.fold_quad_w && !g_first && Mr % 64 == 0) {
+                    // four lanes per output, width-4 NAF against the odd multiples the quads make themselves (k_ipa.cuh k_fold_points_quadw): one list of steps per class
+                    fold_kid = KID_k_fold_points_quadw;
+                    FoldQuadW fq; std::memset(&fq, 0, sizeof fq); fq.Mr = Mr; fq.nterms = nterms;
+                    I.h_qsteps.ensure((size_t)2 * QW_MAXSTEPS * 4); I.qsteps.ensure((size_t)2 * QW_MAXSTEPS * 4);
+                    uint32_t *hs = I.h_qsteps.as<uint32_t>();
+                    double adds_w = 0, dbls_w = 0;
+                    for (uint32_t cls = 0; cls < 2; cls++) {
+                        std::vector<std::array<int8_t, 256>> dg(nterms);
+                        int32_t tp = -1;
+                        for (uint32_t q = 0; q < nterms; q++) {
+                            const uint32_t t = q + 1;
+                            Scalar sc1 = Scalar::one();
+                            for (uint32_t k = 1; k <= g_r; k++) if ((t >> (g_r - k)) & 1u) sc1 = sc1 * (cls ? fH[k - 1] : fG[k - 1]);
+                            tp = std::max(tp, wnaf256(sc1, 4, dg[q].data()));
+                        }
+                        uint32_t ns = 0, pending = 0;
+                        for (int32_t k = tp; k >= 0; k--) {
+                            if (ns) pending++;                              // doubling the identity ahead of the first addition is skipped
+                            for (uint32_t q = 0; q < nterms; q++) {
+                                const int d = dg[q][k];
+                                if (!d) continue;
+                                if (ns >= QW_MAXSTEPS || pending > 255) throw std::logic_error("fold: step list overflow");
+                                const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+                                hs[cls * QW_MAXSTEPS + ns++] = pending | (q << 8) | ((mag >> 1) << 11) | ((d < 0 ? 1u : 0u) << 13);
+                                dbls_w += pending; pending = 0;
+                            }
+                        }
+                        fq.nsteps[cls] = ns; fq.tail[cls] = pending; adds_w += ns; dbls_w += pending;
+                    }
+                    HIPCHK(hipMemcpyAsync(I.qsteps.p, hs, (size_t)2 * QW_MAXSTEPS * 4, hipMemcpyHostToDevice, st));
+                    // the multiples live in the arena: no multiscalar sum of this context is in flight during a fold
+                    I.arena.ensure((size_t)3 * nterms * 2 * Mr * 4 * sizeof(fe));
+                    BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quadw, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, I.qsteps.as<uint32_t>(), reinterpret_cast<fe *>(I.arena_at(0)), fq);
+                    adds_fm = (adds_w * 8.0 + nterms * 2.0 * (7.0 + 8.0 + 7.0 + 2 * 9.0 + 3.0)) * Mr; top = (int32_t)(dbls_w / 2.0) - 1;      // bookkeeping below: field multiplications of the whole launch
+                } else if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad) {
                     fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
                 } else if (2 * Mr <= split_max && nterms >= 3 && nterms <= 15) {
@@ -1648,6 +1701,16 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
             for (uint64_t k = 0; k < nblk; k++) HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
             BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(2 * n, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw), sL, (uint32_t)(2 * n), I.stale_flag.as<uint32_t>());
         } else
+        {
+        // the draws are converted (64 uniform bytes -> a scalar mod l) when somebody needs them: before each piece of S and after the last draw - three launches
+        // for a 2^20-gate proof where rounds 1-4 made one per slab (31), every one of them behind the chain and none of them needed so early
+        uint64_t conv_from = 0;
+        auto convert_to = [&](uint64_t hi) {
+            if (hi <= conv_from) return;
+            const uint32_t *src = bs ? reinterpret_cast<const uint32_t *>(bs->d_raw) : I.raw_rng.as<uint32_t>();
+            BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(hi - conv_from, 256)), dim3(256), src + 16 * conv_from, sL + conv_from, (uint32_t)(hi - conv_from), I.stale_flag.as<uint32_t>());
+            conv_from = hi;
+        };
         for (uint64_t i = 0; i < 2 * n; i += slab) {
             const uint64_t cnt = std::min<uint64_t>(slab, 2 * n - i);
             if (bs) {
@@ -1662,13 +1725,13 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
                     throw DeviceError(std::string("upload of the blinding draws failed: ") + hipGetErrorString((hipError_t)uerr));
                 }
                 HIPCHK(hipStreamWaitEvent(st, (*static_cast<std::vector<hipEvent_t> *>(bs->ev))[k], 0));
-                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), reinterpret_cast<const uint32_t *>(bs->d_raw) + 16 * i, sL + i, (uint32_t)cnt, I.stale_flag.as<uint32_t>());
             } else {
                 rng.fill_draws64(raw + 64 * i, cnt);
                 HIPCHK(hipMemcpyAsync(I.raw_rng.as<uint8_t>() + 64 * i, raw + 64 * i, cnt * 64, hipMemcpyHostToDevice, st));
-                BPG_LAUNCH(I, k_sc_from_wide, dim3(cdiv(cnt, 256)), dim3(256), I.raw_rng.as<uint32_t>() + 16 * i, sL + i, (uint32_t)cnt, I.stale_flag.as<uint32_t>());
             }
-            if (!merged && i + cnt < 2 * n) launch_pieces(i + cnt);
+            if (!merged && i + cnt < 2 * n && next_piece < 3 && pieces[next_piece].b <= i + cnt) { convert_to(i + cnt); launch_pieces(i + cnt); }
+        }
+        convert_to(2 * n);
         }
     }
     if (bs) {   // take the generator back: the state before draw 2n is the last snapshot at or below it, advanced by the remainder
@@ -1737,13 +1800,16 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     const size_t b_w = Impl::al256((c->ncols ? c->ncols : 1) * sizeof(scm)), b_z = Impl::al256((q + 2) * sizeof(scm)), b_y = Impl::al256(N * sizeof(scm));
     I.arena.ensure(b_w + b_z + b_y);
     scm *const wAll_p = reinterpret_cast<scm *>(I.arena_at(0)), *const zpow_p = reinterpret_cast<scm *>(I.arena_at(b_w)), *const ypow_p = reinterpret_cast<scm *>(I.arena_at(b_w + b_z));
-    auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
-        uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
-        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
-    };
-    exp_table(y, ypow_p, N);
-    exp_table(yinv, I.yinvpow.as<scm>(), N);
-    exp_table(z, zpow_p, q + 1);
+    {   // y^i, y^-i, z^j: one launch
+        ExpTables E; std::memset(&E, 0, sizeof E);
+        uint32_t k = 0, lgmax = 0;
+        auto add = [&](const Scalar &base, scm *out, uint64_t count) {
+            uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
+            E.base[k] = to_scm(base); E.out[k] = out; E.count[k] = (uint32_t)count; E.lgT[k] = lgT; lgmax = std::max(lgmax, lgT); k++;
+        };
+        add(y, ypow_p, N); add(yinv, I.yinvpow.as<scm>(), N); add(z, zpow_p, q + 1);
+        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgmax, 256), k), dim3(256), E);
+    }
     if (c->ncols > 1)      // every column but the last (constant terms: verifier only)
         BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(),
                            c->ent_coef.as<uint32_t>(), c->coef.as<scm>(), zpow_p, wAll_p, (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));
@@ -1874,12 +1940,16 @@ R1CSError Engine::verify(DeviceCircuit *c, Transcript &T, const uint8_t *V, cons
     const size_t b_w = Impl::al256(c->ncols * sizeof(scm)), b_z = Impl::al256((q + 2) * sizeof(scm)), b_y = Impl::al256(N * sizeof(scm));
     I.arena.ensure(b_w + b_z + b_y);
     scm *const wAll_p = reinterpret_cast<scm *>(I.arena_at(0)), *const zpow_p = reinterpret_cast<scm *>(I.arena_at(b_w)), *const ypow_p = reinterpret_cast<scm *>(I.arena_at(b_w + b_z));
-    auto exp_table = [&](const Scalar &base, scm *out, uint64_t count) {
-        uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
-        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgT, 256)), dim3(256), to_scm(base), out, (uint32_t)count, lgT);
-    };
-    exp_table(yinv, I.yinvpow.as<scm>(), N);
-    exp_table(z, zpow_p, q + 1);
+    {   // y^-i, z^j: one launch
+        ExpTables E; std::memset(&E, 0, sizeof E);
+        uint32_t k = 0, lgmax = 0;
+        auto add = [&](const Scalar &base, scm *out, uint64_t count) {
+            uint32_t lgT = ceil_log2(count); if (lgT > 16) lgT = 16;
+            E.base[k] = to_scm(base); E.out[k] = out; E.count[k] = (uint32_t)count; E.lgT[k] = lgT; lgmax = std::max(lgmax, lgT); k++;
+        };
+        add(yinv, I.yinvpow.as<scm>(), N); add(z, zpow_p, q + 1);
+        BPG_LAUNCH(I, k_exp_table, dim3(cdiv(1u << lgmax, 256), k), dim3(256), E);
+    }
     if (c->ncols > 1)
         BPG_LAUNCH(I, k_flatten, dim3(cdiv(c->ncols - 1, 256)), dim3(256), c->col_ptr.as<uint64_t>(), c->ent_row.as<uint32_t>(), c->ent_coef.as<uint32_t>(),
                    c->coef.as<scm>(), zpow_p, wAll_p, (uint32_t)(c->ncols - 1), (uint32_t)(3 * n));

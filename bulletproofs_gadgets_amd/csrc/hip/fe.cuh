@@ -346,6 +346,7 @@ BPG_HD fe fe_pow22523(const fe &z) { fe t19, t3; fe_pow22501(t19, t3, z); return
 BPG_HD fe FE_D() { return BPG_FE(0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu); }
 BPG_HD fe FE_D2() { return BPG_FE(0x26b2f159u, 0xebd69b94u, 0x8283b156u, 0x00e0149au, 0xeef3d130u, 0x198e80f2u, 0x56dffce7u, 0x2406d9dcu); }
 BPG_HD fe FE_D4() { return BPG_FE(0x4d65e2b2u, 0xd7ad3728u, 0x050762adu, 0x01c02935u, 0xdde7a260u, 0x331d01e5u, 0xadbff9ceu, 0x480db3b8u); }      // 4d
+BPG_HD fe FE_INV_D() { return BPG_FE(0xcdc9f843u, 0x25e0f276u, 0x4279542eu, 0x0b5dd698u, 0xcdb9cf66u, 0x2b162114u, 0x14d5ce43u, 0x40907ed2u); }      // 1 / d
 BPG_HD fe FE_INV2() { return BPG_FE(0xfffffff7u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu); }    // 1/2 = (p + 1) / 2
 BPG_HD fe FE_SQRTM1() { return BPG_FE(0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u); }
 BPG_HD fe FE_SQRT_AD_MINUS_ONE() { return BPG_FE(0x497b2e1bu, 0x7e97f6a0u, 0x1b7854bdu, 0xaf9d8e0cu, 0x31f5d1fdu, 0x0f3cfcc9u, 0x2b8348acu, 0x376931bfu); }

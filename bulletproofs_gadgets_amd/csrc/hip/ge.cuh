@@ -84,6 +84,12 @@ BPG_HD ge_ext ge_add_pniels_signed(const ge_ext &p, const ge_pniels &q, uint32_t
     return r;
 }
 
+// +-q as an extended point without an addition to the identity: (Y+X) -+ (Y-X) = 2X, 2Y, 2Z and 2dT / d = 2T - the point (2X : 2Y : 2Z : 2T), one product
+BPG_HD ge_ext ge_from_pniels_signed(const ge_pniels &q, uint32_t neg) {
+    ge_ext r; r.X = fe_cneg(fe_sub(q.ypx, q.ymx), neg); r.Y = fe_add(q.ypx, q.ymx); r.Z = fe_add(q.Z, q.Z); r.T = fe_cneg(fe_mul(q.t2d, FE_INV_D()), neg);
+    return r;
+}
+
 // extended -> halved affine Niels given 1 / (2 Z): x/2 = X / (2Z), y/2 = Y / (2Z), d x y = 4d (x/2)(y/2)
 BPG_HD ge_niels ge_to_niels_halfinv(const ge_ext &p, const fe &zinv_half) {
     fe x = fe_mul(p.X, zinv_half), y = fe_mul(p.Y, zinv_half);

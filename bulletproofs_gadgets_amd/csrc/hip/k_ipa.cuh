@@ -195,12 +195,8 @@ __global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ 
             acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
         }
     }
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+    const fe sum = ge_block_sum_quad(acc, lds);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
 }
 // Wide tables for a tail that starts on the ORIGINAL generators (circuits up to 2^14 multipliers freeze at round 0): those never change, so a
 // table of k * 2^(8w) * P (w < 32 windows of 8 bits, k = 1..128, 512 KB per point, built once per device) halves the additions of every round:
@@ -273,12 +269,8 @@ __global__ void __launch_bounds__(256) k_tt_round8(const ge_pniels *__restrict__
             acc = ge_add_pniels_signed(acc, tbl[k * TT8_MULTS + mag - 1], neg);
         }
     }
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+    const fe sum = ge_block_sum_quad(acc, lds);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
 }
 // A_I, A_O, S of a circuit whose generators already have window tables (N <= 2^14: the tables of the frozen IPA tail are those of
 // the original generators and live with the context): blockIdx.y = 0: <a_L,G> + <a_R,H>, 1: <a_O,G>, 2: <s_L,G> + <s_R,H>; same thread
@@ -305,34 +297,30 @@ __global__ void __launch_bounds__(256) k_tt_commit3(const ge_pniels *__restrict_
             acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
         }
     }
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partial[cls * gridDim.x + blockIdx.x] = lds[0];
+    const fe sum = ge_block_sum_quad(acc, lds);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
 }
 // block k: out[k] = sum of partial[k][0..nblk) + blind[k] * (fixed base whose window table is tableX)
 __global__ void __launch_bounds__(256) k_tt_commit3_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ blind,
                                                            const ge_pniels *__restrict__ tableX, ge_ext *__restrict__ out) {
     __shared__ ge_ext lds[256];
     const uint32_t cls = blockIdx.x;
-    ge_ext acc = ge_identity();
-    for (uint32_t s = threadIdx.x; s < nblk; s += 256) acc = ge_add(acc, partial[cls * nblk + s]);
-    if (threadIdx.x < TT_WINDOWS) {
+    ge_ext acc = ge_identity();                              // as in k_tt_finish: first point as it is, the blinding term on the last threads
+    uint32_t s0 = threadIdx.x;
+    if (s0 < nblk) { acc = partial[cls * nblk + s0]; s0 += 256; }
+    for (; s0 < nblk; s0 += 256) acc = ge_add(acc, partial[cls * nblk + s0]);
+    const uint32_t win = 255u - threadIdx.x;
+    if (win < TT_WINDOWS) {
         uint32_t w[8]; tt_biased_words(w, blind[cls]);
-        const int32_t d = (int32_t)((w[threadIdx.x >> 3] >> (4 * (threadIdx.x & 7u))) & 15u) - 8;
+        const int32_t d = (int32_t)((w[win >> 3] >> (4 * (win & 7u))) & 15u) - 8;
         if (d != 0) {
             const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            acc = ge_add_pniels_signed(acc, tableX[threadIdx.x * TT_MULTS + mag - 1], neg);
+            const ge_pniels q = tableX[win * TT_MULTS + mag - 1];
+            acc = threadIdx.x >= nblk ? ge_from_pniels_signed(q, neg) : ge_add_pniels_signed(acc, q, neg);
         }
     }
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[cls] = lds[0];
+    const fe sum = ge_block_sum_quad(acc, lds);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(out + cls)[threadIdx.x] = sum;
 }
 // block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>; the point goes to the host, which encodes it
 __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ a, const scm *__restrict__ b,
@@ -343,22 +331,24 @@ __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ pa
     scm ip = sc_zero();
     for (uint32_t i = threadIdx.x; i < h; i += 256) ip = sc_add(ip, cls == 0 ? sc_mont_mul(a[i], b[h + i]) : sc_mont_mul(a[h + i], b[i]));
     const scm cw = sc_mont_mul(block_sum_256(ip, slds), wq);
+    // a thread's first point is taken as it is (no addition to the identity), and the 64 windows of (c w) B go to the LAST threads of the block, which hold no
+    // partial when nblk <= 192: two dependent additions less ahead of the tree
     ge_ext acc = ge_identity();
-    for (uint32_t s = threadIdx.x; s < nblk; s += 256) acc = ge_add(acc, partial[cls * nblk + s]);
-    if (threadIdx.x < TT_WINDOWS) {
+    uint32_t s0 = threadIdx.x;
+    if (s0 < nblk) { acc = partial[cls * nblk + s0]; s0 += 256; }
+    for (; s0 < nblk; s0 += 256) acc = ge_add(acc, partial[cls * nblk + s0]);
+    const uint32_t win = 255u - threadIdx.x;
+    if (win < TT_WINDOWS) {
         uint32_t w[8]; tt_biased_words(w, cw);
-        const int32_t d = (int32_t)((w[threadIdx.x >> 3] >> (4 * (threadIdx.x & 7u))) & 15u) - 8;
+        const int32_t d = (int32_t)((w[win >> 3] >> (4 * (win & 7u))) & 15u) - 8;
         if (d != 0) {
             const uint32_t neg = d < 0, mag = neg ? (uint32_t)(-d) : (uint32_t)d;
-            acc = ge_add_pniels_signed(acc, tableB[threadIdx.x * TT_MULTS + mag - 1], neg);
+            const ge_pniels q = tableB[win * TT_MULTS + mag - 1];
+            acc = threadIdx.x >= nblk ? ge_from_pniels_signed(q, neg) : ge_add_pniels_signed(acc, q, neg);
         }
     }
-    lds[threadIdx.x] = acc; __syncthreads();
-    for (uint32_t d = 128; d > 0; d >>= 1) {
-        if (threadIdx.x < d) lds[threadIdx.x] = ge_add(lds[threadIdx.x], lds[threadIdx.x + d]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[cls] = lds[0];
+    const fe sum = ge_block_sum_quad(acc, lds);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(out + cls)[threadIdx.x] = sum;
 }
 
 // Pedersen commitments v*B + r*B_blinding from the window tables of the two fixed bases (k_tt_bases / k_tt_multiples on
@@ -625,6 +615,63 @@ __global__ void __launch_bounds__(256) k_fold_points_quad(const ge_niels *__rest
     }
     c = quad_madd(c, quad_load_niels(tab + i, r), 0u, r);
     if (live) reinterpret_cast<fe *>(out + t)[r] = c;        // ge_ext = {X, Y, Z, T}
+}
+
+// The same fold with width-4 NAF digits against the odd multiples 3P, 5P, 7P of every addend (round 5, second session): 51 additions per 253-bit scalar
+// instead of 84 - 253 doublings + 357 additions + ~45 operations to make the multiples, against 253 + 588, on a chain that is the whole kernel.  The multiples are made
+// by the quad itself (P -> 2P -> 3P -> 5P -> 7P), stored as projective operands of quad_madd in a scratch table [entry][output][coordinate] (lanes of a wave read and
+// write consecutive addresses) and read back by the lanes that wrote them; 1P stays in registers.  The host turns the shared scalars into ONE list of steps per class
+// (G, H): step = doublings before the addition | term << 8 | multiple << 11 | sign << 13; the operand of the next step is loaded while the current one is computed.
+// Groups after the first only (no padding class); a block of 64 outputs lies in G or in H (Mr is a multiple of 64).
+#define QW_MAXSTEPS 1024
+struct FoldQuadW { uint32_t Mr, nterms, nsteps[2], tail[2]; };
+__global__ void __launch_bounds__(256) k_fold_points_quadw(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, ge_ext *__restrict__ out /* 2*Mr */,
+                                                           const uint32_t *__restrict__ steps /* [2][QW_MAXSTEPS] */, fe *tabq /* [3*nterms][2*Mr][4] */, const FoldQuadW fg) {
+    const uint32_t r = threadIdx.x & 3u;
+    const uint32_t t = blockIdx.x * 64 + (threadIdx.x >> 2);              // 2*Mr is a multiple of 64: every quad is live
+    const uint32_t isH = (blockIdx.x * 64u >= fg.Mr) ? 1u : 0u;           // block-uniform
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const ge_niels *tab = isH ? H : G;
+    const uint32_t NT = fg.nterms;                                        // <= 7
+#define BPG_QFOLD_LOAD(j) fe q##j = fe_zero(); if (j <= NT) q##j = quad_load_niels(tab + i + (size_t)j * fg.Mr, r);
+    BPG_QFOLD_VARS(BPG_QFOLD_LOAD)
+#undef BPG_QFOLD_LOAD
+    const size_t stride = (size_t)2 * fg.Mr * 4;                          // field elements per table entry
+    fe *mine = tabq + (size_t)t * 4 + r;
+#define BPG_QFOLD_BUILD(j) if (j <= NT) { \
+        const fe P = quad_madd(quad_identity(r), q##j, 0u, r), D = quad_dbl(P, r); \
+        fe M = quad_madd(D, q##j, 0u, r);  mine[(size_t)(3 * (j - 1) + 0) * stride] = quad_to_operand(M, r); \
+        M = quad_add(M, D, r);             mine[(size_t)(3 * (j - 1) + 1) * stride] = quad_to_operand(M, r); \
+        M = quad_add(M, D, r);             mine[(size_t)(3 * (j - 1) + 2) * stride] = quad_to_operand(M, r); }
+    BPG_QFOLD_VARS(BPG_QFOLD_BUILD)
+#undef BPG_QFOLD_BUILD
+    const uint32_t *st = steps + isH * QW_MAXSTEPS;
+    const uint32_t ns = fg.nsteps[isH];
+    auto operand = [&](uint32_t s) -> fe {                                // s is the wave's
+        const uint32_t q = (s >> 8) & 7u, m = (s >> 11) & 3u;
+        if (m) return mine[(size_t)(3 * q + m - 1) * stride];
+        fe Q = q1;
+        switch (q) {
+#define BPG_QFOLD_PICK(j) case j - 1: Q = q##j; break;
+            BPG_QFOLD_VARS(BPG_QFOLD_PICK)
+#undef BPG_QFOLD_PICK
+            default: break;
+        }
+        return Q;
+    };
+    fe c = quad_identity(r);
+    uint32_t snext = ns ? (uint32_t)__builtin_amdgcn_readfirstlane(st[0]) : 0u;
+    fe nxt = ns ? operand(snext) : fe_zero();
+    for (uint32_t k = 0; k < ns; k++) {
+        const uint32_t s = snext;
+        const fe op = nxt;
+        if (k + 1 < ns) { snext = (uint32_t)__builtin_amdgcn_readfirstlane(st[k + 1]); nxt = operand(snext); }
+        for (uint32_t d = s & 255u; d > 0; d--) c = quad_dbl(c, r);
+        c = quad_madd(c, op, (s >> 13) & 1u, r);
+    }
+    for (uint32_t d = fg.tail[isH]; d > 0; d--) c = quad_dbl(c, r);
+    c = quad_madd(c, quad_load_niels(tab + i, r), 0u, r);
+    reinterpret_cast<fe *>(out + t)[r] = c;                               // ge_ext = {X, Y, Z, T}
 }
 
 // Latency variant of the same fold for small tables (2*Mr <= 64 K outputs: one wave per SIMD at most, so the kernel is one

@@ -49,9 +49,9 @@ __device__ __forceinline__ void msm_biased_words(uint32_t w[8], const scm &sc, c
 // A one-level counting sort (round 1; removed in round 4) writes every entry with its own 4-byte store at a position nobody else of the block
 // writes near (a tile holds about one entry per bucket): 8x write amplification, and a histogram matrix of tiles x buckets that is read and
 // written three times.  Two levels instead:
-//   k_msm_digits    every signed digit of every term once: dig[window][term] = digit + 2^15  (2 bytes, coalesced; digits of windows up to 16 bits
-//                   wide lie in [-2^15, 2^15), 2^15 = no entry)
-//   k_msm_count1    block (tile of 2^lgTile terms, window): LDS histogram over the CB coarse bins (top bits of the bucket index)
+//   k_msm_digits    block (tile of 2^lgTile terms): every signed digit of every term once: dig[window][term] = digit + 2^15  (2 bytes, coalesced; digits of
+//                   windows up to 16 bits wide lie in [-2^15, 2^15), 2^15 = no entry), and an LDS histogram per window over the CB coarse bins (top bits of
+//                   the bucket index) while the digits are in registers
 //   (scan)          exclusive scan of counts1[(msm*W + window)*CB + bin][tile] in that order: where each (bin, tile) run starts
 //   k_msm_scatter1  block (tile, window): orders its entries by coarse bin in LDS and copies the runs out - consecutive lanes write
 //                   consecutive addresses; entry = neg << 31 | fine << (31 - fb) | segment << (27 - fb) | index in segment
@@ -73,22 +73,6 @@ __device__ __forceinline__ uint32_t msm_lds_take(uint32_t *ctr, uint32_t key, bo
     }
     return active ? atomicAdd(&ctr[key], 1u) : 0u;
 }
-__global__ void __launch_bounds__(256) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ heavy_count,
-                                                    uint32_t *__restrict__ medium_count) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
-    if (g >= total) return;
-    const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
-    const uint32_t *skip = S.skip[s];
-    if (skip && ((skip[i >> 5] >> (i & 31u)) & 1u)) {         // merged away (its scalar rides on another term of this sum): no entry in any window
-        for (uint32_t j = 0; j < P.W; j++) dig[(size_t)j * total + g] = (uint16_t)32768;
-        return;
-    }
-    uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
-    for (uint32_t j = 0; j < P.W; j++) {
-        dig[(size_t)j * total + g] = (uint16_t)(msm_digit_biased(w, P.W, j) + 32768);
-    }
-}
 // stored digit -> |digit| (0 = no entry) and sign
 __device__ __forceinline__ uint32_t msm_dig_mag(uint32_t x) { return x >= 32768u ? x - 32768u : 32768u - x; }
 __device__ __forceinline__ uint32_t msm_dig_neg(uint32_t x) { return x < 32768u ? 1u : 0u; }
@@ -101,22 +85,36 @@ __device__ __forceinline__ void msm_tile_of(const MsmPlan &P, uint32_t T, uint32
     g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
 }
 #define MSM_CB_MAX 512
-__global__ void __launch_bounds__(256) k_msm_count1(MsmPlan P, const uint16_t *__restrict__ dig, uint32_t total, uint32_t *__restrict__ counts1) {
-    __shared__ uint32_t hist[MSM_CB_MAX];
+// Digits and coarse histograms in one launch (rounds 2-4: k_msm_digits over the terms, then k_msm_count1 over (tile, window) re-reading the digits).  Block = one tile
+// of 2^lgTile terms (tiles never span two sums): a thread converts its four terms once, writes their W digits (coalesced per window) and counts each in the LDS
+// histogram of its window - W x CB counters, dynamic LDS (17 x 128 for a 2^21-term sum).
+__global__ void __launch_bounds__(1024) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ counts1,
+                                                    uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ medium_count) {
+    extern __shared__ uint32_t hist[];                       // [W][CB]
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
     uint32_t m, t, g0, g1; msm_tile_of(P, blockIdx.x, m, t, g0, g1);
-    const uint32_t win = blockIdx.y, mw = m * P.W + win;
-    for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) hist[b] = 0;
+    const uint32_t nh = P.W * P.CB;
+    for (uint32_t b = threadIdx.x; b < nh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    const uint16_t *D = dig + (size_t)win * total;
-    for (uint32_t gb = g0 + threadIdx.x; gb < g1 + 63u; gb += 4u * blockDim.x) {  // whole waves take part in the ballot of msm_lds_take; four loads in flight
-        uint32_t m4[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) { const uint32_t g = gb + u * blockDim.x; m4[u] = g < g1 ? msm_dig_mag(D[g]) : 0u; }
-#pragma unroll
-        for (uint32_t u = 0; u < 4; u++) (void)msm_lds_take(hist, m4[u] ? (m4[u] - 1u) >> P.fb : 0u, m4[u] != 0u);
+    // 1,024 threads, four terms each: the kernel is the terms' arithmetic (a Montgomery conversion and W digits), it wants the SIMDs full.  The counters are
+    // incremented without their values coming back (no slot is taken here: k_msm_scatter1 takes them), so lanes with one key cost a wave 64 cycles, not a round trip each
+    for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+        const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+        const uint32_t *skip = S.skip[s];
+        const bool live = !(skip && ((skip[i >> 5] >> (i & 31u)) & 1u));            // a skipped term was merged away (its scalar rides on another term of this sum): no entry in any window
+        uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
+        for (uint32_t j = 0; j < P.W; j++) {
+            const uint32_t d = live ? (uint32_t)(msm_digit_biased(w, P.W, j) + 32768) : 32768u;
+            dig[(size_t)j * total + g] = (uint16_t)d;
+            const uint32_t mag = msm_dig_mag(d);
+            if (mag) atomicAdd(&hist[j * P.CB + ((mag - 1u) >> P.fb)], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < P.CB; b += blockDim.x) counts1[((size_t)mw * P.CB + b) * P.tmax + t] = hist[b];
+    for (uint32_t b = threadIdx.x; b < nh; b += blockDim.x) {
+        const uint32_t j = b / P.CB, bin = b - j * P.CB;
+        counts1[((size_t)(m * P.W + j) * P.CB + bin) * P.tmax + t] = hist[b];
+    }
 }
 #define MSM_TILE1_MAX 4096
 #define MSM_TILE1_PER (MSM_TILE1_MAX / 256)
@@ -231,7 +229,9 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
     }
 }
 
-// exclusive scan of counts[0..nkeys) in three launches (chunk = 2048 keys per block)
+// exclusive scan of counts[0..nkeys) in two launches (chunk = 2048 keys per block): the block sums, then every block adds up the block sums before it
+// (a few thousand values for the sums of a 2^20-gate proof, read from L2) and scans its own chunk - no serial pass over the block sums in between
+// (rounds 1-4 had a one-wave launch for it: twelve launches per proof with nothing else to run beside them)
 #define SCAN_CHUNK 2048
 __global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restrict__ counts, uint32_t nkeys, uint32_t *__restrict__ blocksum) {
     __shared__ uint32_t lds[256];
@@ -241,24 +241,15 @@ __global__ void __launch_bounds__(256) k_scan_blocksums(const uint32_t *__restri
     for (uint32_t d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d]; __syncthreads(); }
     if (threadIdx.x == 0) blocksum[blockIdx.x] = lds[0];
 }
-// exclusive scan of the block sums in place (blocksum[nblocks] = grand total): ONE wave; lane l owns the contiguous slice
-// [l*per, (l+1)*per), sums it, the 64 slice sums are scanned with shuffles, then each lane rewrites its slice
-__global__ void __launch_bounds__(64) k_scan_top(uint32_t *__restrict__ blocksum, uint32_t nblocks) {
-    if (blockIdx.x != 0) return;
-    const uint32_t lane = threadIdx.x & 63u, per = (nblocks + 63u) / 64u;
-    const uint32_t b0 = min(lane * per, nblocks), b1 = min(b0 + per, nblocks);
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += blocksum[b];
-    uint32_t incl = sum;
-#pragma unroll
-    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-    uint32_t run = incl - sum;
-    for (uint32_t b = b0; b < b1; b++) { const uint32_t v = blocksum[b]; blocksum[b] = run; run += v; }
-    if (lane == 63) blocksum[nblocks] = incl;
-}
 __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__ counts, uint32_t nkeys, const uint32_t *__restrict__ blocksum,
                                                     uint32_t *__restrict__ starts, uint32_t *__restrict__ cursor) {
     __shared__ uint32_t lds[256];
+    uint32_t pre = 0;
+    for (uint32_t b = threadIdx.x; b < blockIdx.x; b += 256) pre += blocksum[b];
+    lds[threadIdx.x] = pre; __syncthreads();
+    for (uint32_t d = 128; d > 0; d >>= 1) { if (threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d]; __syncthreads(); }
+    const uint32_t before = lds[0];
+    __syncthreads();
     uint32_t base = blockIdx.x * SCAN_CHUNK;
     uint32_t v[8], s = 0;                       // thread owns 8 consecutive keys
 #pragma unroll
@@ -268,14 +259,14 @@ __global__ void __launch_bounds__(256) k_scan_apply(const uint32_t *__restrict__
         uint32_t x = threadIdx.x >= d ? lds[threadIdx.x - d] : 0; __syncthreads();
         lds[threadIdx.x] += x; __syncthreads();
     }
-    uint32_t run = blocksum[blockIdx.x] + lds[threadIdx.x] - s;
+    uint32_t run = before + lds[threadIdx.x] - s;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         uint32_t idx = base + threadIdx.x * 8 + k;
         if (idx < nkeys) { starts[idx] = run; cursor[idx] = run; }
         run += v[k];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) starts[nkeys] = blocksum[gridDim.x];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) starts[nkeys] = run;      // the grand total
 }
 
 // Balanced bucket sweep.  The entry list is sorted by bucket (starts[]); thread c adds the points of the fixed-size chunk
@@ -456,10 +447,6 @@ __global__ void __launch_bounds__(64) k_bucket_reduce(const ge_ext *__restrict__
     partial[t] = acc; partial[(size_t)total + t] = run;
 }
 __device__ __forceinline__ ge_ext ge_dbl_times(ge_ext p, uint32_t k) { for (uint32_t i = 0; i < k; i++) p = ge_dbl(p); return p; }
-__device__ __forceinline__ fe fe_shfl_down(const fe &a, uint32_t d) { fe r;
-#pragma unroll
-    for (int j = 0; j < 8; j++) r.v[j] = __shfl_down(a.v[j], d, 64);
-    return r; }
 __device__ __forceinline__ ge_ext ge_shfl_down(const ge_ext &p, uint32_t d) {
     ge_ext r; r.X = fe_shfl_down(p.X, d); r.Y = fe_shfl_down(p.Y, d); r.Z = fe_shfl_down(p.Z, d); r.T = fe_shfl_down(p.T, d); return r; }
 // lane l <- sum_{l' >= l} of the wave (lanes >= n hold the identity)
@@ -512,6 +499,101 @@ __global__ void __launch_bounds__(512) k_window_sums(const ge_ext *__restrict__ 
         if (wv == 0) { X = lane < nw ? ldsT[lane] : ge_identity(); X = ge_wave_sum(X, lane, nw); }
     }
     if (threadIdx.x == 0) wsum[blockIdx.x] = X;
+}
+
+// The same sums for a proof ALONE on the device (round 5, second session): k_window_sums is a chain of ~35 dependent point additions per window on 34 CUs (two waves
+// per SIMD, 6.8 us per addition); here a point has FOUR lanes (k_points.cuh quad_*: ~750 instructions per addition on the wave instead of ~1,650) and a window
+// is spread over several blocks, one wave per SIMD on the whole device.  Grid (nblk, windows), 256 threads = 64 slots; slot s of block beta owns the segments
+// t = (beta * 64 + s) * per + i, i < per.  Stage A, per block: U = sum acc_t + seg * sum (t - t0) run_t and Rt = sum run_t (running sums in the slot, suffix scan
+// and tree over the slots as in k_window_sums).  A window of one block is done; otherwise the block that finishes LAST (a ticket per window; agent-scope stores,
+// fence, atomic) repeats the slot-level step on the nblk pairs: S = sum U_beta + seg * span * sum beta Rt_beta.  More instructions than k_window_sums: a proof that
+// shares the device keeps that one.
+// slots of a block, (Q_s, R_s) in quad layout -> slot 0 of wave 0: Q = sum_s Q_s + 2^shift * sum_s s R_s, R = sum_s R_s.  nw waves take part (1, or the
+// block's 4: block-uniform), n16 live slots per wave (a power of two <= 16; the slots beyond hold the identity)
+__device__ __forceinline__ void wq_combine(fe &Q, fe &R, uint32_t shift, uint32_t nw, uint32_t n16, fe (*ldsT)[4], fe (*ldsU)[4], uint32_t r, uint32_t wv, uint32_t s16) {
+    fe S = R;                                                       // suffix sums of R over the wave's slots, then over the waves
+    for (uint32_t d = 1; d < n16; d <<= 1) { const fe o = fe_shfl_down(S, 4u * d); const fe t = quad_add(S, o, r); S = fe_select(S, t, s16 + d < n16); }
+    if (nw > 1) {
+        if (s16 == 0) ldsT[wv][r] = S;
+        __syncthreads();
+        if (wv + 1 < nw) {                                          // wave-uniform
+            fe h = ldsT[nw - 1][r];
+            for (uint32_t w2 = nw - 2; w2 > wv; w2--) h = quad_add(h, ldsT[w2][r], r);
+            S = quad_add(S, h, r);
+        }
+    }
+    R = S;
+    fe D = S;
+    for (uint32_t i = 0; i < shift; i++) D = quad_dbl(D, r);
+    const fe X = quad_add(Q, D, r);
+    Q = fe_select(X, Q, wv == 0 && s16 == 0);                       // the block's first slot has weight 0
+    for (uint32_t d = n16 >> 1; d > 0; d >>= 1) { const fe o = fe_shfl_down(Q, 4u * d); Q = quad_add(Q, o, r); }
+    if (nw > 1) {
+        if (s16 == 0) ldsU[wv][r] = Q;
+        __syncthreads();
+        if (wv == 0) {
+            fe v = s16 < nw ? ldsU[s16][r] : quad_identity(r);
+            for (uint32_t d = nw >> 1; d > 0; d >>= 1) { const fe o = fe_shfl_down(v, 4u * d); v = quad_add(v, o, r); }
+            Q = v;
+        }
+    }
+}
+__device__ __forceinline__ void wq_store(ge_ext *p, uint32_t r, const fe &c) {           // coordinate r, visible to the other blocks of the kernel
+    uint32_t *w = reinterpret_cast<uint32_t *>(reinterpret_cast<fe *>(p) + r);
+#pragma unroll
+    for (int j = 0; j < 8; j++) __hip_atomic_store(w + j, c.v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ fe wq_load(const ge_ext *p, uint32_t r) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const fe *>(p) + r);
+    fe c;
+#pragma unroll
+    for (int j = 0; j < 8; j++) c.v[j] = __hip_atomic_load(w + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return c;
+}
+__global__ void __launch_bounds__(256) k_window_sums_quad(const ge_ext *__restrict__ partial, ge_ext *__restrict__ wsum, ge_ext *stage /* [window][nblk][2] */,
+                                                          uint32_t *tickets /* [window], zero between launches */, uint32_t nseg_per_win, uint32_t total,
+                                                          uint32_t lgseg, uint32_t lgper) {
+    __shared__ fe ldsT[4][4], ldsU[4][4];
+    __shared__ uint32_t is_last;
+    const uint32_t r = threadIdx.x & 3u, slot = threadIdx.x >> 2, wv = threadIdx.x >> 6, s16 = slot & 15u;
+    const uint32_t win = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x, per = 1u << lgper;
+    const ge_ext *A = partial + (size_t)win * nseg_per_win, *Rn = A + total;
+    const uint32_t t0 = (blk * 64u + slot) * per;
+    fe Q = quad_identity(r), R = Q;
+    if (t0 < nseg_per_win) {                                        // the same for the four lanes of a slot
+        R = quad_load_ext(Rn + t0 + per - 1, r); Q = quad_load_ext(A + t0 + per - 1, r);
+        if (per > 1) {                                              // zero-based running sum from the top, as in k_window_sums
+            fe Z = R;
+            for (uint32_t k = per - 1; k-- > 0;) {
+                R = quad_add(R, quad_load_ext(Rn + t0 + k, r), r); Q = quad_add(Q, quad_load_ext(A + t0 + k, r), r);
+                if (k > 0) Z = quad_add(Z, R, r);
+            }
+            for (uint32_t i = 0; i < lgseg; i++) Z = quad_dbl(Z, r);
+            Q = quad_add(Q, Z, r);
+        }
+    }
+    wq_combine(Q, R, lgseg + lgper, 4u, 16u, ldsT, ldsU, r, wv, s16);
+    if (nblk == 1) { if (threadIdx.x < 4) reinterpret_cast<fe *>(wsum + win)[r] = Q; return; }
+    ge_ext *mine = stage + ((size_t)win * nblk + blk) * 2;
+    if (threadIdx.x < 4) { wq_store(mine, r, Q); wq_store(mine + 1, r, R); }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t t = atomicAdd(&tickets[win], 1u);
+        is_last = t == nblk - 1u ? 1u : 0u;
+        if (t == nblk - 1u) tickets[win] = 0;                       // every other block of the window has taken its ticket
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // stage B: the nblk (U, Rt) pairs of the window, one per slot; block beta's segments start at beta * 64 * per
+    const uint32_t nwB = nblk > 16u ? 4u : 1u, n16B = nblk > 16u ? 16u : nblk;
+    if (wv >= nwB) return;
+    const ge_ext *all = stage + (size_t)win * nblk * 2;
+    Q = quad_identity(r); R = Q;
+    if (slot < nblk) { Q = wq_load(all + 2 * slot, r); R = wq_load(all + 2 * slot + 1, r); }
+    wq_combine(Q, R, lgseg + lgper + 6u, nwB, n16B, ldsT, ldsU, r, wv, s16);
+    if (threadIdx.x < 4) reinterpret_cast<fe *>(wsum + win)[r] = Q;
 }
 
 // The recombination of the W window sums, sum_j 2^off(j) * S_j (about 254 dependent doublings of one point), runs on the host

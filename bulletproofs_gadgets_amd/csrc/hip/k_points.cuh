@@ -46,6 +46,56 @@ __device__ __forceinline__ fe quad_madd(const fe &c, const fe &qv, uint32_t neg,
     // X3 = E * F, Y3 = G * H, Z3 = F * G, T3 = E * H
     return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
 }
+// full addition (ge_add, 9M) of two points that are both spread over the quad: c, e = coordinate r of P, Q -> coordinate r of P + Q.  Three rounds of
+// products: (A, B, T1 T2, Z1 Z2), then the constants (1, 1, 2d, 2) - C = 2d T1 T2 and D = 2 Z1 Z2 in one round - then the four output products.
+// About 750 instructions on the wave against ~1,650 of ge_add.  Every lane of the quad must be active (DPP reads inside the quad).
+__device__ __forceinline__ fe quad_add(const fe &c, const fe &e, uint32_t r) {
+    const fe X1 = quad_get<0>(c), Y1 = quad_get<1>(c), X2 = quad_get<0>(e), Y2 = quad_get<1>(e);
+    const fe lhs = quad_pick(r, fe_sub(Y1, X1), fe_add(Y1, X1), quad_get<3>(c), quad_get<2>(c));      // (Y1 - X1, Y1 + X1, T1, Z1)[r]
+    const fe rhs = quad_pick(r, fe_sub(Y2, X2), fe_add(Y2, X2), quad_get<3>(e), quad_get<2>(e));
+    fe k = fe_zero(); k.v[0] = r == 3u ? 2u : 1u;
+    const fe p = fe_mul(fe_mul(lhs, rhs), fe_select(k, FE_D2(), r == 2u));
+    const fe A = quad_get<0>(p), B = quad_get<1>(p), C = quad_get<2>(p), D = quad_get<3>(p);
+    const fe E = fe_sub(B, A), F = fe_sub(D, C), G = fe_add(D, C), H = fe_add(B, A);
+    return fe_mul(quad_pick(r, E, G, F, E), quad_pick(r, F, H, G, H));
+}
+// coordinate r of P -> lane r's operand of quad_madd for the PROJECTIVE point P: ((Y - X)/2, (Y + X)/2, d T, Z)[r] (one round of products by constants);
+// with it quad_madd computes D = Z1 Z2 where an affine operand gives D = Z1 - the same halved formulas, 8M
+__device__ __forceinline__ fe quad_to_operand(const fe &c, uint32_t r) {
+    const fe X = quad_get<0>(c), Y = quad_get<1>(c);
+    const fe v = quad_pick(r, fe_sub(Y, X), fe_add(Y, X), quad_get<3>(c), quad_get<2>(c));
+    return fe_mul(v, quad_pick(r, FE_INV2(), FE_INV2(), FE_D(), fe_one()));
+}
+__device__ __forceinline__ fe quad_identity(uint32_t r) { fe c = fe_zero(); c.v[0] = (r == 1u || r == 2u) ? 1u : 0u; return c; }      // (0, 1, 1, 0)[r]
+__device__ __forceinline__ fe quad_load_ext(const ge_ext *p, uint32_t r) { return reinterpret_cast<const fe *>(p)[r]; }              // ge_ext = {X, Y, Z, T}
+__device__ __forceinline__ fe fe_shfl_down(const fe &a, uint32_t d) { fe r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) r.v[j] = __shfl_down(a.v[j], d, 64);
+    return r; }
+// Sum of the 256 points of a block, one per thread (the end of every table-driven kernel of the tail: rounds 1-4 ran a binary tree through LDS, eight dependent
+// ge_add of 4.2 us each with most of the block idle).  The points go through LDS into quad layout - slot s = threads 4s .. 4s+3 takes points 4s .. 4s+3, three
+// additions - then four shuffle levels inside each wave and two across the waves: nine quad additions of about half the length.  lds: 256 points; the block's
+// threads all call it; coordinate r of the sum is returned in threads r = 0 .. 3.
+__device__ __forceinline__ fe ge_block_sum_quad(const ge_ext &acc, ge_ext *lds) {
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    const uint32_t r = threadIdx.x & 3u, slot = threadIdx.x >> 2, s16 = slot & 15u, wv = threadIdx.x >> 6;
+    const fe *L = reinterpret_cast<const fe *>(lds);
+    fe c = L[(4 * slot + 0) * 4 + r];
+#pragma unroll 1
+    for (uint32_t k = 1; k < 4; k++) c = quad_add(c, L[(4 * slot + k) * 4 + r], r);
+    for (uint32_t d = 8; d > 0; d >>= 1) { const fe o = fe_shfl_down(c, 4u * d); c = quad_add(c, o, r); }
+    __syncthreads();                                            // every slot has read its points: the first 16 field elements are reused
+    fe *Wt = reinterpret_cast<fe *>(lds);
+    if (s16 == 0) Wt[wv * 4 + r] = c;
+    __syncthreads();
+    if (wv == 0) {
+        fe v = s16 < 4 ? Wt[s16 * 4 + r] : quad_identity(r);
+        for (uint32_t d = 2; d > 0; d >>= 1) { const fe o = fe_shfl_down(v, 4u * d); v = quad_add(v, o, r); }
+        c = v;
+    }
+    return c;
+}
 __device__ __forceinline__ fe quad_load_niels(const ge_niels *p, uint32_t r) {     // lane r's operand of quad_madd
     const fe *f = reinterpret_cast<const fe *>(p);                                 // ge_niels = {(y + x)/2, (y - x)/2, dxy}
     return r == 3u ? fe_one() : f[r == 0u ? 1 : (r == 1u ? 0 : 2)];

@@ -79,12 +79,15 @@ __global__ void __launch_bounds__(256) k_blind_expand(const BlindHead head, scm 
     for (int k = 0; k < 8; k++) { w[2 * k] = (uint32_t)a[k]; w[2 * k + 1] = (uint32_t)(a[k] >> 32); }
     out[j] = sc_from_wide_words(w);
 }
-// out[i] = base^i for i < count (Montgomery form). Thread t walks i = t, t+T, ... multiplying by base^T; T = 2^lgT.
-__global__ void __launch_bounds__(256) k_exp_table(scm base, scm *__restrict__ out, uint32_t count, uint32_t lgT) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t T = 1u << lgT;
+// out[i] = base^i for i < count (Montgomery form), for up to three tables in one launch (blockIdx.y picks the table: y^i, y^-i and z^i of a proof).
+// Thread t walks i = t, t+T, ... multiplying by base^T; T = 2^lgT.
+struct ExpTables { scm base[3]; scm *out[3]; uint32_t count[3], lgT[3]; };
+__global__ void __launch_bounds__(256) k_exp_table(ExpTables E) {
+    const uint32_t k = blockIdx.y;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, lgT = E.lgT[k], T = 1u << lgT, count = E.count[k];
     if (t >= T) return;
-    scm cur = SC_R1(), sq = base;
+    scm *__restrict__ out = E.out[k];
+    scm cur = SC_R1(), sq = E.base[k];
     for (uint32_t b = 0; b < lgT; b++) {           // cur = base^t ; sq ends as base^T
         if ((t >> b) & 1u) cur = sc_mont_mul(cur, sq);
         sq = sc_mont_mul(sq, sq);

@@ -2,7 +2,7 @@
 // no MFMA - this is 255-bit modular arithmetic, not a dense contraction.  Hot-path rows of SURVEY.md section 8(a):
 //   a7  BulletproofGens::new            k_gens_derive + k_normalize_niels
 //   a1-a3,a6  Pedersen commits          k_pedersen (window tables of B and B_blinding: k_tt_bases, k_tt_multiples)
-//   a9  A_I, A_O, S multiscalar muls    k_msm_digits, k_msm_count1, k_scan_*, k_msm_scatter1, k_msm_sort2 (two-level sort), k_bucket_chunks,
+//   a9  A_I, A_O, S multiscalar muls    k_msm_digits, k_scan_*, k_msm_scatter1, k_msm_sort2 (two-level sort), k_bucket_chunks,
 //                                       k_bucket_combine(_per_bucket, _heavy), k_bucket_reduce, k_window_sums
 //                                       (bucket method: digits -> coarse partition in LDS -> fine counting sort -> balanced bucket sweep -> reductions;
 //                                       the 17 window sums are recombined and encoded on the host, host/fe51.hpp)

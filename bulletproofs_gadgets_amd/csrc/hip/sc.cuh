@@ -149,8 +149,27 @@ BPG_HD scm sc_from_wide_words(const uint32_t *w) {
     return sc_add(sc_mont_mul(lo, SC_RR()), sc_mont_mul(hi, SC_RRR()));
 }
 // Montgomery form -> canonical integer words
+// = a / 2^256 mod l: the Montgomery REDUCTION alone (a product by one spends 64 multiply-adds on zeros: ~330 instructions, this is ~190; every term of every
+// multiscalar sum and every thread of the table-driven tail converts its scalar).  Eight steps, each adds m * l with m = t0 * (-1/l) so that the low limb
+// vanishes; l has five non-zero limbs.  a < l, so the result is below l + 1: one conditional subtraction.
 BPG_HD void sc_to_words(uint32_t *w, const scm &a) {
-    scm r = sc_mont_mul(a, sc_plain_one());
+    const uint32_t L0 = 0x5cf5d3edu, L1 = 0x5812631au, L2 = 0xa2f79cd6u, L3 = 0x14def9deu, L7 = 0x10000000u;
+    uint32_t t[9];
+    BPG_UNROLL for (int i = 0; i < 8; i++) t[i] = a.v[i];
+    t[8] = 0;
+    BPG_UNROLL for (int i = 0; i < 8; i++) {
+        const uint32_t m = t[0] * BPG_SC_NINV;
+        uint64_t c = ((uint64_t)t[0] + (uint64_t)m * L0) >> 32;
+        c += (uint64_t)t[1] + (uint64_t)m * L1; t[0] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)t[2] + (uint64_t)m * L2; t[1] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)t[3] + (uint64_t)m * L3; t[2] = (uint32_t)c; c >>= 32;
+        c += t[4]; t[3] = (uint32_t)c; c >>= 32;
+        c += t[5]; t[4] = (uint32_t)c; c >>= 32;
+        c += t[6]; t[5] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)t[7] + (uint64_t)m * L7; t[6] = (uint32_t)c; c >>= 32;
+        c += t[8]; t[7] = (uint32_t)c; t[8] = (uint32_t)(c >> 32);
+    }
+    const scm r = sc_cond_sub(t);
     BPG_UNROLL for (int i = 0; i < 8; i++) w[i] = r.v[i];
 }
 

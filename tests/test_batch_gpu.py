@@ -177,3 +177,27 @@ def test_rccl_collectives_beside_engine_streams(tmp_path):
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "rccl ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plan_only_reads_the_node_from_sysfs_without_touching_the_gpu():
+    """`bench.py --gpus N --plan-only` (the 8-GPU readiness check of a node nobody can run the real bench on yet): on a box with a card the topology comes from
+    sysfs - the card's PCI address and NUMA node as torch reports them for device 0 - and the plan names cores, chain-pool lanes, expected HBM and pinned host
+    memory per rank; the process never loads torch or the library (no HIP call)."""
+    import json
+    import subprocess
+    import sys
+    bench = str(pathlib.Path(__file__).resolve().parent.parent / "bench.py")
+    r = subprocess.run([sys.executable, "-X", "importtime", bench, "--gpus", "1", "--plan-only"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "torch" not in r.stderr and "bulletproofs_gadgets_amd" not in r.stderr          # -X importtime lists every module the process imported
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    assert plan["plan_only"] and plan["topology"]["source"] == "sysfs" and len(plan["ranks"]) == 1
+    # torch in a process of its own: this one has the library's HIP runtime loaded, and torch's bundled one then sees no device
+    q = subprocess.run([sys.executable, "-c", "import torch; p = torch.cuda.get_device_properties(0); "
+                        "print('%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id))"], capture_output=True, text=True, timeout=300)
+    assert q.returncode == 0, q.stderr[-2000:]
+    assert plan["ranks"][0]["pci"] == q.stdout.strip().splitlines()[-1]
+    rank = plan["ranks"][0]
+    assert rank["proving_streams"] == 20 and sum(rank["chain_pool_lanes"]) <= 20 and 30 < rank["hbm_expected_GB"] < 288 and plan["fits"]["hbm_per_card"]
+

@@ -188,12 +188,15 @@ def test_msm_with_wide_windows_on_small_sums(cmin, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"BPG_RSEG": "1"}, {"BPG_RSEG": "2"}, {"BPG_RSEG": "64"}, {"BPG_RSEG": "1024"}, {"BPG_LGCH": "2"}, {"BPG_LGCH": "7"},
                                  {"BPG_SWEEP_RESIDENT": "64"}, {"BPG_SWEEP_RESIDENT": "4096", "BPG_FOLD_ADAPT": "2"}, {"BPG_FOLD_ADAPT": "2", "BPG_RSEG": "16"},
-                                 {"BPG_FOLD_ADAPT": "0", "BPG_MSM_CMAX": "12"}])
+                                 {"BPG_FOLD_ADAPT": "0", "BPG_MSM_CMAX": "12"},
+                                 {"BPG_WINDOW_QUAD": "0"}, {"BPG_WINDOW_QUAD_BLOCKS": "1"}, {"BPG_WINDOW_QUAD_BLOCKS": "65536"},
+                                 {"BPG_WINDOW_QUAD_BLOCKS": "65536", "BPG_RSEG": "1"}, {"BPG_WINDOW_QUAD_BLOCKS": "40", "BPG_RSEG": "2"}])
 def test_msm_epilogue_and_sweep_knobs_give_the_oracle_sum(env, monkeypatch):
     """The diagnostic knobs of the bucket-method MSM - BPG_RSEG (buckets per thread of the first level of the window epilogue), BPG_LGCH (chunk
     length of the sweep), BPG_SWEEP_RESIDENT (blocks the device is taken to hold), BPG_FOLD_ADAPT = 2 (the shared-device variants: 16-bit windows,
-    64-entry chunks, 256-thread window blocks) - change how the sum is scheduled, never its value: windows from 2 to 16 bits wide, with and
-    without whole empty segments, identical scalars in one bucket, against the oracle."""
+    64-entry chunks, 256-thread window blocks), BPG_WINDOW_QUAD / BPG_WINDOW_QUAD_BLOCKS (the window sums of a proof alone with four lanes per point:
+    off; one block per window; up to 64 blocks per window, whose last one runs the second stage on one or on four waves) - change how the sum is
+    scheduled, never its value: windows from 2 to 16 bits wide, with and without whole empty segments, identical scalars in one bucket, against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     for cmin in ("2", "11", "16"):
@@ -251,6 +254,42 @@ def test_equal_scalar_merging_changes_no_byte(merge, monkeypatch):
         check_against_oracle(c, p, t, [], 128)
         if merge != "0":
             assert c.schedule()["merged_last"] == 7                                # the five value classes of a_L (the one of 40 members as two groups) and the (x, x) pair; a_O = x y: all different
+    finally:
+        c.close()
+
+
+def test_one_context_interleaves_sizes_and_entry_points():
+    """The large buffers of a context share ONE arena (engine.hip: an MSM's digits and entry lists, the sweep's partial sums, the polynomial phase's weights and
+    powers, the tail's window tables take it in turn) and the window tables of the ORIGINAL generators of a small circuit live beside it and outlive the proof.
+    On one context: a 2^16 proof (bucket-method sums, tail tables in the arena), its verification (one MSM over the arena), a 2^12 proof (table-driven from round
+    0: tables of its own), a raw MSM, the 2^16 proof again, the small one again, an upload in between - every result equals the oracle's or the first run's."""
+    c = bpg.Context(0)
+    try:
+        big = workloads.mimc_preimage(c, nbytes=2130, seed=31, label=b"MiMCHash")            # n = 65,124, N = 2^16
+        small = workloads.mimc_preimage(c, nbytes=100, seed=32, label=b"MiMCHash")           # n = 3,888, N = 2^12
+        bi, bs = big.prover.instance(), big.transcript.state
+        si, ss = small.prover.instance(), small.transcript.state
+        c.gens_ensure(big.gens_capacity)
+        rb, rs_ = c.upload(bi), c.upload(si)
+        seed = bytes([7]) * 32
+        rc, want_small, _ = O.prove(O.Gens(small.gens_capacity), ss, to_oracle(si), si.v_blinding, seed, O.FLAG_FAST_MSM)
+        assert rc == 0
+        first_big = rb.prove(bs, bi.v_blinding, seed, 0)[0]
+        assert O.verify(O.Gens(big.gens_capacity), bs, to_oracle(bi), b"".join(big.commitments), first_big) == 0
+        G, Hh = c.gens_export(5, 300)
+        s = [rs(b"is", i) for i in range(300)]; t = [rs(b"it", i) for i in range(300)]
+        want_msm = O.msm(b"".join(s + t), G + Hh, 1)
+        for rep in range(2):
+            assert rb.verify(bs, b"".join(big.commitments), first_big) == 0
+            assert rs_.prove(ss, si.v_blinding, seed, 0)[0] == want_small
+            assert c.msm_gens(5, s, t) == want_msm
+            assert rb.prove(bs, bi.v_blinding, seed, 0)[0] == first_big
+            assert rs_.verify(ss, b"".join(small.commitments), want_small) == 0
+            r2 = c.upload(bi)                                                               # an upload's workspace is the arena too
+            assert r2.prove(bs, bi.v_blinding, seed, 0)[0] == first_big
+            r2.free()
+            assert rs_.prove(ss, si.v_blinding, seed, 0)[0] == want_small
+        rb.free(); rs_.free()
     finally:
         c.close()
 
@@ -559,6 +598,31 @@ def test_tail_start_of_folded_and_of_original_generators(tt_lg, orig_lg, monkeyp
                 rc, want, st_want = O.prove(O.Gens(a.gens_capacity), a.transcript.state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
                 assert rc == 0 and proof == want and st_after == st_want, (tt_lg, orig_lg, inst.n)
             res.free()
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("quadw", ["1", "0"])
+@pytest.mark.parametrize("group", [1, 2, 3])
+def test_small_folds_with_and_without_the_quads_own_multiples(group, quadw, monkeypatch):
+    """k_fold_points_quadw (a proof alone, groups after the first, Mr a multiple of 64): width-4 NAF steps against 3P, 5P, 7P that each quad makes and stores
+    itself, one step list per class - with one, three and seven terms per output (groups of 1, 2, 3 rounds on N = 4096: folds to 2048 ... 64 generators
+    take it, the smaller ones the register form) - and BPG_FOLD_QUAD_W=0 (plain NAF, addends in registers): the oracle's bytes either way."""
+    monkeypatch.setenv("BPG_TT_LG", "0")
+    monkeypatch.setenv("BPG_FOLD_GROUP", str(group))
+    monkeypatch.setenv("BPG_FOLD_QUAD_W", quadw)
+    c = bpg.Context(0)
+    try:
+        a = workloads.mimc_preimage(c, nbytes=100, seed=32, label=b"MiMCHash")            # n = 3,888, N = 2^12
+        inst = a.prover.instance()
+        assert a.gens_capacity == 4096
+        c.gens_ensure(4096)
+        res = c.upload(inst)
+        for seed in (bytes(range(32)), bytes([5]) * 32):
+            proof, st_after = res.prove(a.transcript.state, inst.v_blinding, seed, 0)
+            rc, want, st_want = O.prove(O.Gens(4096), a.transcript.state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
+            assert rc == 0 and proof == want and st_after == st_want, (group, quadw)
+        res.free()
     finally:
         c.close()
 
