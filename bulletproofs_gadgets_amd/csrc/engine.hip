@@ -208,7 +208,7 @@ struct DeviceCircuit {
 // kernel ids for the optional HIP-event profile (bpg_profile_*)
 #define BPG_KERNELS(X) X(k_gens_derive) X(k_normalize_niels) X(k_compress_niels) X(k_pedersen) X(k_sc_from_bytes) \
     X(k_sc_from_wide) X(k_blind_poison) X(k_exp_table) X(k_reduce_partials) X(k_flatten) X(k_flatten_const) X(k_poly_t) X(k_poly_eval) X(k_ipa_prep) \
-    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_fold_points_quadw) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) \
+    X(k_ipa_fold_scalars) X(k_fold_points) X(k_fold_points_reg) X(k_fold_points_split) X(k_fold_points_wnaf) X(k_fold_points_quad) X(k_fold_points_quadw) X(k_fold_points_regw) X(k_odd_start) X(k_odd_start_ext) X(k_dbl_times) X(k_odd_step) X(k_msm_digits) X(k_msm_scatter1) X(k_msm_sort2) X(k_scan_blocksums) \
     X(k_scan_apply) X(k_bucket_chunks) X(k_bucket_combine) X(k_bucket_combine_heavy) X(k_bucket_reduce) X(k_window_sums) X(k_window_sums_quad) X(k_decompress) X(k_ipa_s) X(k_verify_scalars) X(k_bench_fe_mul) \
     X(k_tt_bases) X(k_tt_multiples) X(k_tt_bases8) X(k_tt_multiples8) X(k_tt_round8) X(k_tt_factors) X(k_tt_advance) X(k_tt_round) X(k_tt_finish) X(k_blind_expand) X(k_tt_commit3) X(k_tt_commit3_finish) X(k_csc_count) X(k_csc_fill) X(k_csc_colptr) X(k_merge_insert) X(k_merge_plan) X(k_merge_groups) X(k_merge_members) X(k_merge_sum)
 enum KernelId {
@@ -433,6 +433,7 @@ struct Engine::Impl {
     bool shared_variants() const { return fold_adapt == 2 || (fold_adapt == 1 && device_shared(shared->device)); }
     bool fold_quad = true;          // small folds: four lanes per output (BPG_FOLD_QUAD=0: the four-wave split kernel)
     bool fold_quad_w = true;        // ... with width-4 NAF against multiples the quads make themselves, in the groups after the first (BPG_FOLD_QUAD_W=0: plain NAF, addends in registers)
+    bool fold_reg_w = true;         // the same steps with one lane per output where the register kernels would run (BPG_FOLD_REG_W=0: plain NAF, addends in registers)
     bool window_quad = true;        // window sums of a proof alone: four lanes per point, several blocks per window (BPG_WINDOW_QUAD=0: k_window_sums always)
     uint32_t window_quad_blocks = 288;   // ... at most this many blocks of four waves per launch (about one wave per SIMD on 256 CUs; BPG_WINDOW_QUAD_BLOCKS)
     uint32_t fold_group = 3;        // rounds per generator fold (BPG_FOLD_GROUP overrides, 1..5)
@@ -587,6 +588,7 @@ Engine::Engine(int device, const EngineConfig &cfg) : device_(device) {
     env_set("BPG_FOLD_SPLIT", 0, 1 << 24, K->fold_split_max);
     if (env_present("BPG_FOLD_QUAD")) K->fold_quad = env_int_strict("BPG_FOLD_QUAD", 0, 1) != 0;
     if (env_present("BPG_FOLD_QUAD_W")) K->fold_quad_w = env_int_strict("BPG_FOLD_QUAD_W", 0, 1) != 0;
+    if (env_present("BPG_FOLD_REG_W")) K->fold_reg_w = env_int_strict("BPG_FOLD_REG_W", 0, 1) != 0;
     if (env_present("BPG_WINDOW_QUAD")) K->window_quad = env_int_strict("BPG_WINDOW_QUAD", 0, 1) != 0;
     env_set("BPG_WINDOW_QUAD_BLOCKS", 1, 65536, K->window_quad_blocks);
     env_set("BPG_FOLD_ADAPT", 0, 2, K->fold_adapt);
@@ -1394,10 +1396,10 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 ge_ext *fo = I.scratch_ext.as<ge_ext>(); const uint32_t *nf = I.naf.as<uint32_t>();
                 const bool regs = nterms == 1 || nterms == 3 || nterms == 7 || nterms == 15;
                 const uint32_t split_max = (regs && I.shared_now) ? 0 : I.fold_split_max;    // other proofs fill the device: fewest instructions
-                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad && I.fold_quad_w && !g_first && Mr % 64 == 0) {
-                    // four lanes per output, width-4 NAF against the odd multiples the quads make themselves (k_ipa.cuh k_fold_points_quadw): one list of steps per class
-                    fold_kid = KID_k_fold_points_quadw;
-                    FoldQuadW fq; std::memset(&fq, 0, sizeof fq); fq.Mr = Mr; fq.nterms = nterms;
+                // width-4 NAF steps against odd multiples that the fold kernel makes itself (k_ipa.cuh k_fold_points_quadw / _regw): one list of steps per class (G, H),
+                // the multiples in the arena - no multiscalar sum of this context is in flight during a fold
+                FoldQuadW fq; std::memset(&fq, 0, sizeof fq); fq.Mr = Mr; fq.nterms = nterms;
+                auto make_steps = [&]() {
                     I.h_qsteps.ensure((size_t)2 * QW_MAXSTEPS * 4); I.qsteps.ensure((size_t)2 * QW_MAXSTEPS * 4);
                     uint32_t *hs = I.h_qsteps.as<uint32_t>();
                     double adds_w = 0, dbls_w = 0;
@@ -1425,16 +1427,24 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                         fq.nsteps[cls] = ns; fq.tail[cls] = pending; adds_w += ns; dbls_w += pending;
                     }
                     HIPCHK(hipMemcpyAsync(I.qsteps.p, hs, (size_t)2 * QW_MAXSTEPS * 4, hipMemcpyHostToDevice, st));
-                    // the multiples live in the arena: no multiscalar sum of this context is in flight during a fold
-                    I.arena.ensure((size_t)3 * nterms * 2 * Mr * 4 * sizeof(fe));
+                    I.arena.ensure((size_t)3 * nterms * 2 * Mr * sizeof(ge_pniels));
+                    // bookkeeping below: field multiplications of the whole launch (8 per addition against a projective multiple; P, 2P, 3P, 5P, 7P and three conversions per term)
+                    adds_fm = (adds_w * 8.0 + nterms * 2.0 * (7.0 + 8.0 + 7.0 + 2 * 9.0 + 3.0)) * Mr; top = (int32_t)(dbls_w / 2.0) - 1;
+                };
+                if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad && I.fold_quad_w && !g_first && Mr % 64 == 0) {
+                    fold_kid = KID_k_fold_points_quadw;    // four lanes per output
+                    make_steps();
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quadw, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, I.qsteps.as<uint32_t>(), reinterpret_cast<fe *>(I.arena_at(0)), fq);
-                    adds_fm = (adds_w * 8.0 + nterms * 2.0 * (7.0 + 8.0 + 7.0 + 2 * 9.0 + 3.0)) * Mr; top = (int32_t)(dbls_w / 2.0) - 1;      // bookkeeping below: field multiplications of the whole launch
                 } else if (2 * Mr <= split_max && nterms >= 1 && nterms <= 7 && I.fold_quad) {
                     fold_kid = KID_k_fold_points_quad;     // four lanes per output (kernels: k_points.cuh quad_*, k_ipa.cuh)
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_quad, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
                 } else if (2 * Mr <= split_max && nterms >= 3 && nterms <= 15) {
                     fold_kid = KID_k_fold_points_split;
                     BPG_LAUNCH_ID(I, fold_kid, k_fold_points_split, dim3(cdiv(2 * Mr, 64)), block, Gst, Hst, fo, nf, fg);
+                } else if (2 * Mr > split_max && I.fold_reg_w && !g_first && nterms >= 1 && nterms <= 7 && Mr % 256 == 0) {
+                    fold_kid = KID_k_fold_points_regw;     // one lane per output, every operand from memory: fewest instructions (a device shared with other proofs)
+                    make_steps();
+                    BPG_LAUNCH_ID(I, fold_kid, k_fold_points_regw, grid, block, Gst, Hst, fo, I.qsteps.as<uint32_t>(), reinterpret_cast<ge_pniels *>(I.arena_at(0)), fq);
                 } else if (regs) {
                     fold_kid = KID_k_fold_points_reg;
                     if (nterms == 1) BPG_LAUNCH_ID(I, fold_kid, k_fold_points_reg<1>, grid, block, Gst, Hst, fo, nf, fg);

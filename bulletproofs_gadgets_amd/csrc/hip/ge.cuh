@@ -84,6 +84,11 @@ BPG_HD ge_ext ge_add_pniels_signed(const ge_ext &p, const ge_pniels &q, uint32_t
     return r;
 }
 
+// the affine (halved) Niels point as an extended point: x = (y+x)/2 - (y-x)/2, y likewise, z = 1, t = x y = (d x y) / d: one product
+BPG_HD ge_ext ge_from_niels(const ge_niels &q) {
+    ge_ext r; r.X = fe_sub(q.ypx, q.ymx); r.Y = fe_add(q.ypx, q.ymx); r.Z = fe_one(); r.T = fe_mul(q.t2d, FE_INV_D());
+    return r;
+}
 // +-q as an extended point without an addition to the identity: (Y+X) -+ (Y-X) = 2X, 2Y, 2Z and 2dT / d = 2T - the point (2X : 2Y : 2Z : 2T), one product
 BPG_HD ge_ext ge_from_pniels_signed(const ge_pniels &q, uint32_t neg) {
     ge_ext r; r.X = fe_cneg(fe_sub(q.ypx, q.ymx), neg); r.Y = fe_add(q.ypx, q.ymx); r.Z = fe_add(q.Z, q.Z); r.T = fe_cneg(fe_mul(q.t2d, FE_INV_D()), neg);

@@ -674,6 +674,60 @@ __global__ void __launch_bounds__(256) k_fold_points_quadw(const ge_niels *__res
     reinterpret_cast<fe *>(out + t)[r] = c;                               // ge_ext = {X, Y, Z, T}
 }
 
+// The same steps with ONE lane per output and every operand read from memory when its step comes up (the shape for a device that other proofs share: fewest
+// instructions - 253 doublings + ~51 additions per term + 44 multiplications per term for its multiples, against 253 + 84 per term with the addends in
+// registers: -15 % at seven terms).  Lane i of a wave reads entry e of output i: [entry][output] layout, consecutive lanes read consecutive points; 1P is the
+// group-start table itself (halved affine Niels, 7M), 3P, 5P, 7P are projective Niels operands (8M).  The operand of the next step is loaded while the current one
+// is added.  A block of 256 outputs lies in G or in H (Mr is a multiple of 256).
+struct fold_operand { fe a, b, z, c; };                       // (ypx, ymx, Z, t2d) of a projective multiple; (ypx, ymx, -, t2d) of a table point (halved)
+__global__ void __launch_bounds__(256) k_fold_points_regw(const ge_niels *__restrict__ G, const ge_niels *__restrict__ H, ge_ext *__restrict__ out /* 2*Mr */,
+                                                          const uint32_t *__restrict__ steps /* [2][QW_MAXSTEPS] */, ge_pniels *tabw /* [3*nterms][2*Mr] */, const FoldQuadW fg) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;                    // 2*Mr is a multiple of 256: every lane is live
+    const uint32_t isH = (blockIdx.x * 256u >= fg.Mr) ? 1u : 0u;          // block-uniform
+    const uint32_t i = isH ? t - fg.Mr : t;
+    const ge_niels *tab = isH ? H : G;
+    const size_t stride = (size_t)2 * fg.Mr;
+    ge_pniels *mine = tabw + t;
+#pragma unroll 1
+    for (uint32_t j = 0; j < fg.nterms; j++) {
+        const ge_niels q = tab[i + (size_t)(j + 1) * fg.Mr];
+        const ge_ext D = ge_dbl(ge_from_niels(q));
+        ge_ext M = ge_madd(D, q);  mine[(size_t)(3 * j + 0) * stride] = ge_to_pniels(M);
+        M = ge_add(M, D);          mine[(size_t)(3 * j + 1) * stride] = ge_to_pniels(M);
+        M = ge_add(M, D);          mine[(size_t)(3 * j + 2) * stride] = ge_to_pniels(M);
+    }
+    const uint32_t *st = steps + isH * QW_MAXSTEPS;
+    const uint32_t ns = fg.nsteps[isH];
+    auto operand = [&](uint32_t s) -> fold_operand {                      // s is the wave's
+        const uint32_t q = (s >> 8) & 7u, m = (s >> 11) & 3u;
+        fold_operand o;
+        if (m) { const ge_pniels p = mine[(size_t)(3 * q + m - 1) * stride]; o.a = p.ypx; o.b = p.ymx; o.z = p.Z; o.c = p.t2d; }
+        else { const ge_niels p = tab[i + (size_t)(q + 1) * fg.Mr]; o.a = p.ypx; o.b = p.ymx; o.z = fe_one(); o.c = p.t2d; }
+        return o;
+    };
+    ge_ext acc = ge_identity();
+    uint32_t snext = ns ? (uint32_t)__builtin_amdgcn_readfirstlane(st[0]) : 0u;
+    fold_operand nxt; nxt.a = nxt.b = nxt.z = nxt.c = fe_zero();
+    if (ns) nxt = operand(snext);
+    for (uint32_t k = 0; k < ns; k++) {
+        const uint32_t s = snext;
+        const fold_operand op = nxt;
+        if (k + 1 < ns) { snext = (uint32_t)__builtin_amdgcn_readfirstlane(st[k + 1]); nxt = operand(snext); }
+        for (uint32_t d = s & 255u; d > 0; d--) acc = ge_dbl(acc);
+        const uint32_t neg = (s >> 13) & 1u;                              // the wave's: scalar branches, no selects
+        if ((s >> 11) & 3u) {
+            ge_pniels p; p.Z = op.z;
+            if (neg) { p.ypx = op.b; p.ymx = op.a; p.t2d = fe_neg(op.c); } else { p.ypx = op.a; p.ymx = op.b; p.t2d = op.c; }
+            acc = ge_add_pniels_signed(acc, p, 0u);
+        } else {
+            ge_niels p; p.ypx = op.a; p.ymx = op.b; p.t2d = op.c;
+            if (neg) acc = ge_msub(acc, p); else acc = ge_madd(acc, p);
+        }
+    }
+    for (uint32_t d = fg.tail[isH]; d > 0; d--) acc = ge_dbl(acc);
+    out[t] = ge_madd(acc, tab[i]);
+}
+
 // Latency variant of the same fold for small tables (2*Mr <= 64 K outputs: one wave per SIMD at most, so the kernel is one
 // dependent chain of 253 doublings + nterms * 84 additions whatever it does): the terms of an output are dealt to the FOUR
 // waves of a block (term q goes to wave q mod 4), each wave runs its own chain of doublings over its <= 4 addends with

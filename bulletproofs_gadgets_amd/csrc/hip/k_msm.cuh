@@ -386,26 +386,24 @@ __global__ void __launch_bounds__(256) k_bucket_combine_per_bucket(const uint32_
     for (uint32_t c = c0 + 1; c <= c1; c++) acc = ge_add(acc, slotA[c]);
     buckets[k] = acc;
 }
-// one wave per heavy bucket (grid-stride over the list): lane-strided partial sums, then a 6-level tree through LDS; then the medium list, one thread per bucket
+// one BLOCK per heavy bucket (grid-stride over the list): thread-strided partial sums, then the block sum in quad layout (k_points.cuh ge_block_sum_quad) - the
+// 55,000 padding terms of a 2^20-gate proof's first inner-product round are one bucket of 1,600 pieces per window: 6 additions per thread and the tree, where a
+// single wave (rounds 1-4) ran 25 and a tree of its own, 130 us on the critical path of the round; then the medium list, one thread per bucket
 __global__ void __launch_bounds__(256) k_bucket_combine_heavy(const uint32_t *__restrict__ starts, ge_ext *__restrict__ buckets,
                                                               const ge_ext *__restrict__ slotA, const ge_ext *__restrict__ slotB,
                                                               uint32_t CH, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ medium) {
     __shared__ ge_ext lds[256];
-    const uint32_t count = heavy[0], lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    ge_ext *L = lds + wv * 64;
-    for (uint32_t it = blockIdx.x * 4 + wv; it < count; it += gridDim.x * 4) {      // wave-uniform trip count; no block barrier inside
+    const uint32_t count = heavy[0];
+    for (uint32_t it = blockIdx.x; it < count; it += gridDim.x) {                    // block-uniform trip count
         const uint32_t k = heavy[1 + it];
-        const uint32_t c0 = starts[k] / CH, c1 = (starts[k + 1] - 1) / CH;
-        ge_ext acc = lane == 0 ? slotB[c0] : ge_identity();
-        for (uint32_t c = c0 + 1 + lane; c <= c1; c += 64) acc = ge_add(acc, slotA[c]);
-        L[lane] = acc;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t d = 32; d > 0; d >>= 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (lane < d) L[lane] = ge_add(L[lane], L[lane + d]);
-        }
-        if (lane == 0) buckets[k] = L[0];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t c0 = starts[k] / CH, c1 = (starts[k + 1] - 1) / CH, P = c1 - c0 + 1;      // pieces: slotB[c0], slotA[c0 + 1 .. c1]
+        ge_ext acc = ge_identity();
+        uint32_t p = threadIdx.x;
+        if (p < P) { acc = p ? slotA[c0 + p] : slotB[c0]; p += 256; }                // a thread's first piece as it is
+        for (; p < P; p += 256) acc = ge_add(acc, slotA[c0 + p]);
+        const fe sum = ge_block_sum_quad(acc, lds);
+        if (threadIdx.x < 4) reinterpret_cast<fe *>(buckets + k)[threadIdx.x] = sum;
+        __syncthreads();                                                             // lds is reused by the next bucket
     }
     // the medium list of k_bucket_combine: buckets[k] already holds the first two pieces; one thread adds the remaining ones
     const uint32_t mcount = medium[0];

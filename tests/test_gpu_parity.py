@@ -602,27 +602,30 @@ def test_tail_start_of_folded_and_of_original_generators(tt_lg, orig_lg, monkeyp
         c.close()
 
 
-@pytest.mark.parametrize("quadw", ["1", "0"])
+@pytest.mark.parametrize("env", [{}, {"BPG_FOLD_QUAD_W": "0"}, {"BPG_FOLD_ADAPT": "2"}, {"BPG_FOLD_ADAPT": "2", "BPG_FOLD_REG_W": "0"}])
 @pytest.mark.parametrize("group", [1, 2, 3])
-def test_small_folds_with_and_without_the_quads_own_multiples(group, quadw, monkeypatch):
-    """k_fold_points_quadw (a proof alone, groups after the first, Mr a multiple of 64): width-4 NAF steps against 3P, 5P, 7P that each quad makes and stores
-    itself, one step list per class - with one, three and seven terms per output (groups of 1, 2, 3 rounds on N = 4096: folds to 2048 ... 64 generators
-    take it, the smaller ones the register form) - and BPG_FOLD_QUAD_W=0 (plain NAF, addends in registers): the oracle's bytes either way."""
+def test_small_folds_on_multiples_the_kernel_makes_itself(group, env, monkeypatch):
+    """k_fold_points_quadw (a proof alone: four lanes per output) and k_fold_points_regw (BPG_FOLD_ADAPT=2, the shared-device variants: one lane per output)
+    fold the groups after the first on width-4 NAF steps against 3P, 5P, 7P that the kernel makes and stores itself, one step list per class - with one,
+    three and seven terms per output (groups of 1, 2, 3 rounds on N = 4096 and N = 16384: the folds whose outputs fill whole blocks take them, the smaller
+    ones the register forms) - and with both switched off (plain NAF, addends in registers): the oracle's bytes every time."""
     monkeypatch.setenv("BPG_TT_LG", "0")
     monkeypatch.setenv("BPG_FOLD_GROUP", str(group))
-    monkeypatch.setenv("BPG_FOLD_QUAD_W", quadw)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     c = bpg.Context(0)
     try:
-        a = workloads.mimc_preimage(c, nbytes=100, seed=32, label=b"MiMCHash")            # n = 3,888, N = 2^12
-        inst = a.prover.instance()
-        assert a.gens_capacity == 4096
-        c.gens_ensure(4096)
-        res = c.upload(inst)
-        for seed in (bytes(range(32)), bytes([5]) * 32):
-            proof, st_after = res.prove(a.transcript.state, inst.v_blinding, seed, 0)
-            rc, want, st_want = O.prove(O.Gens(4096), a.transcript.state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
-            assert rc == 0 and proof == want and st_after == st_want, (group, quadw)
-        res.free()
+        for nbytes, cap in ((100, 4096), (500, 16384)):                                    # n = 3,888 and n = 15,552
+            a = workloads.mimc_preimage(c, nbytes=nbytes, seed=32, label=b"MiMCHash")
+            inst = a.prover.instance()
+            assert a.gens_capacity == cap
+            c.gens_ensure(cap)
+            res = c.upload(inst)
+            for seed in (bytes(range(32)), bytes([5]) * 32)[:2 if cap == 4096 else 1]:
+                proof, st_after = res.prove(a.transcript.state, inst.v_blinding, seed, 0)
+                rc, want, st_want = O.prove(O.Gens(cap), a.transcript.state, to_oracle(inst), inst.v_blinding, seed, O.FLAG_FAST_MSM)
+                assert rc == 0 and proof == want and st_after == st_want, (group, env, cap)
+            res.free()
     finally:
         c.close()
 

@@ -425,7 +425,7 @@ def test_config_struct_matches_the_header_and_pool_api_without_a_gpu(tmp_path):
 @pytest.mark.parametrize("var,val", [("BPG_MERGE", "3"), ("BPG_MERGE", "yes"), ("BPG_RSEG", "0"), ("BPG_RSEG", "3"), ("BPG_RSEG", "abc"), ("BPG_RSEG", "2048"), ("BPG_RSEG", "8x"), ("BPG_LGCH", "1"), ("BPG_LGCH", "zz"),
                                      ("BPG_SWEEP_RESIDENT", "0"), ("BPG_MSM_CMAX", "17"), ("BPG_MSM_CMIN", ""), ("BPG_FOLD_GROUP", "6"), ("BPG_FOLD_WNAF", "2"),
                                      ("BPG_FOLD_PARTS", "3"), ("BPG_TT_LG", "-1"), ("BPG_TABLE_GB", "-4"), ("BPG_FOLD_TABLE_GB", "nan"), ("BPG_CHAIN_LANES", "9"),
-                                     ("BPG_SYNC_BLOCKING", "2"), ("BPG_FOLD_ADAPT", "3"), ("BPG_WINDOW_QUAD", "2"), ("BPG_WINDOW_QUAD_BLOCKS", "0"), ("BPG_FOLD_QUAD_W", "on")])
+                                     ("BPG_SYNC_BLOCKING", "2"), ("BPG_FOLD_ADAPT", "3"), ("BPG_WINDOW_QUAD", "2"), ("BPG_WINDOW_QUAD_BLOCKS", "0"), ("BPG_FOLD_QUAD_W", "on"), ("BPG_FOLD_REG_W", "-1")])
 def test_bad_environment_knobs_are_refused_at_context_creation(var, val, monkeypatch):
     """Every BPG_* knob is read once, when the context is created, BEFORE the device is touched: a value that does not parse or is out of range is
     BPG_ERR_INVALID_ARGUMENT from bpg_ctx_create - with or without a GPU - never a silent default and never a fault on the hot path (round 3 read
