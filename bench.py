@@ -240,11 +240,18 @@ def discover_topology(gpus):
                 if not (cls.startswith("0x0302") or cls.startswith("0x0380") or cls.startswith("0x1200")):
                     continue
                 node = int((d / "numa_node").read_text())
-                devs.append({"pci": d.name, "numa_node": max(node, 0)})
+                # a container may be given some of the node's cards only: a card counts when its render node can be opened (what the runtime will find)
+                render = sorted((d / "drm").glob("renderD*")) if (d / "drm").is_dir() else []
+                usable = None if not render else any(os.access("/dev/dri/" + r.name, os.R_OK | os.W_OK) for r in render)
+                devs.append({"pci": d.name, "numa_node": max(node, 0), "usable": usable})
             except Exception:       # noqa: BLE001
                 continue
     except Exception:       # noqa: BLE001
         return None
+    if any(x["usable"] for x in devs):
+        devs = [x for x in devs if x["usable"]]
+    for x in devs:
+        x.pop("usable", None)
     if len(devs) < gpus:
         return None
     nodes = {}

@@ -972,7 +972,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         blocksum.ensure((size_t)(nblk1 + 1) * 4);
         HIPCHK(hipMemsetAsync(counts.p, 0, (size_t)nflat * 4, st));        // tiles an MSM does not have (tmax is the longest MSM's count)
         if ((size_t)W * P.CB * 4 > 64 * 1024) throw std::logic_error("msm: coarse histograms exceed the LDS of a block");
-        BPG_LAUNCH_LDS((*this), KID_k_msm_digits, k_msm_digits, dim3(ntiles ? ntiles : 1), dim3(1024), (size_t)W * P.CB * 4, S, P, total, digits_p, counts.as<uint32_t>(), heavy.as<uint32_t>(), medium.as<uint32_t>());
+        BPG_LAUNCH_LDS((*this), KID_k_msm_digits, k_msm_digits, dim3(ntiles ? ntiles : 1), dim3(512), (size_t)W * P.CB * 4, S, P, total, digits_p, counts.as<uint32_t>(), heavy.as<uint32_t>(), medium.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_blocksums, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>());
         BPG_LAUNCH((*this), k_scan_apply, dim3(nblk1), dim3(256), counts.as<uint32_t>(), nflat, blocksum.as<uint32_t>(), starts1.as<uint32_t>(), cursor.as<uint32_t>());
         if (ntiles) BPG_LAUNCH((*this), k_msm_scatter1, dim3(ntiles, W), dim3(256), S, P, digits_p, total, starts1.as<uint32_t>(), entries1_p);

@@ -86,9 +86,9 @@ __device__ __forceinline__ void msm_tile_of(const MsmPlan &P, uint32_t T, uint32
 }
 #define MSM_CB_MAX 512
 // Digits and coarse histograms in one launch (rounds 2-4: k_msm_digits over the terms, then k_msm_count1 over (tile, window) re-reading the digits).  Block = one tile
-// of 2^lgTile terms (tiles never span two sums): a thread converts its four terms once, writes their W digits (coalesced per window) and counts each in the LDS
+// of 2^lgTile terms (tiles never span two sums): a thread converts its eight terms once, writes their W digits (coalesced per window) and counts each in the LDS
 // histogram of its window - W x CB counters, dynamic LDS (17 x 128 for a 2^21-term sum).
-__global__ void __launch_bounds__(1024) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ counts1,
+__global__ void __launch_bounds__(512) k_msm_digits(MsmSegs S, MsmPlan P, uint32_t total, uint16_t *__restrict__ dig, uint32_t *__restrict__ counts1,
                                                     uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ medium_count) {
     extern __shared__ uint32_t hist[];                       // [W][CB]
     if (blockIdx.x == 0 && threadIdx.x == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
@@ -96,8 +96,10 @@ __global__ void __launch_bounds__(1024) k_msm_digits(MsmSegs S, MsmPlan P, uint3
     const uint32_t nh = P.W * P.CB;
     for (uint32_t b = threadIdx.x; b < nh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    // 1,024 threads, four terms each: the kernel is the terms' arithmetic (a Montgomery conversion and W digits), it wants the SIMDs full.  The counters are
-    // incremented without their values coming back (no slot is taken here: k_msm_scatter1 takes them), so lanes with one key cost a wave 64 cycles, not a round trip each
+    // 512 threads, eight terms each: the kernel is the terms' arithmetic (a Montgomery reduction and W digits) and wants every tile of a 2^21-term sum resident at
+    // once - 512 blocks, two per CU at four waves per SIMD (1,024 threads per block needed eight waves per SIMD, which its register count does not allow: the blocks
+    // ran in two rounds).  The counters are incremented without their values coming back (no slot is taken here: k_msm_scatter1 takes them), so lanes with one key
+    // cost a wave 64 cycles, not a round trip each
     for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
         const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
         const uint32_t *skip = S.skip[s];
