@@ -935,6 +935,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         }
         if (P.tmax == 0) P.tmax = 1;
         for (uint32_t j = 0; j < W; j++) { const uint32_t bit = ((j + 1) * 254u) / W - 1; P.bias[bit >> 5] |= 1u << (bit & 31); }
+        for (uint32_t j = 0; j <= W; j++) P.off[j] = (uint8_t)((j * 254u) / W);
     }
     const uint32_t ntiles = P.tile_start[nmsm];
     starts.ensure((size_t)(nkeys + 1) * 4);

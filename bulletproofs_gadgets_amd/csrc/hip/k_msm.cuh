@@ -8,13 +8,6 @@ namespace bpg {
 // (almost) a full width of entropy - with fixed c-bit windows the last one holds only 253 mod c bits and a handful of
 // buckets would receive every term.  Signed digits: digit j in (-2^(wd-1), 2^(wd-1)], wd = width of window j.
 __device__ __forceinline__ uint32_t msm_off(uint32_t j, uint32_t W) { return (j * 254u) / W; }
-__device__ __forceinline__ int32_t msm_digit(const uint32_t w[8], uint32_t W, uint32_t win, uint32_t &carry) {
-    uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
-    uint64_t two = (uint64_t)(wi < 8 ? w[wi] : 0u) | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
-    uint32_t raw = (uint32_t)((two >> sh) & ((1u << wd) - 1u)) + carry;
-    if (raw > (1u << (wd - 1))) { carry = 1; return (int32_t)raw - (int32_t)(1u << wd); }
-    carry = 0; return (int32_t)raw;
-}
 __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
     uint32_t s = 0;
 #pragma unroll
@@ -29,13 +22,14 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
     uint32_t nmsm, W, nb, lgTile, tmax;
+    uint8_t off[132];            // off[j] = first bit of window j, j <= W (msm_off; the host fills it: a division by W per digit was two thirds of k_msm_digits' instructions)
     uint32_t fb, CB;             // two-level sort: a bucket index splits into CB coarse bins x 2^fb fine slots (nb = CB << fb)
     uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
     uint32_t tile_start[5];      // first tile of MSM m
     uint32_t bias[8];
 };
-__device__ __forceinline__ int32_t msm_digit_biased(const uint32_t w[8], uint32_t W, uint32_t win) {
-    const uint32_t off = msm_off(win, W), wd = msm_off(win + 1, W) - off, wi = off >> 5, sh = off & 31;
+__device__ __forceinline__ int32_t msm_digit_biased(const uint32_t w[8], const MsmPlan &P, uint32_t win) {
+    const uint32_t off = P.off[win], wd = P.off[win + 1] - off, wi = off >> 5, sh = off & 31;
     const uint64_t two = (uint64_t)w[wi] | ((uint64_t)(wi + 1 < 8 ? w[wi + 1] : 0u) << 32);
     return (int32_t)((uint32_t)(two >> sh) & ((1u << wd) - 1u)) - (int32_t)(1u << (wd - 1));
 }
@@ -85,6 +79,7 @@ __device__ __forceinline__ void msm_tile_of(const MsmPlan &P, uint32_t T, uint32
     g1 = min(g0 + (1u << P.lgTile), P.term_start[m + 1]);
 }
 #define MSM_CB_MAX 512
+#define MSM_DIG_PER 8                    // terms per thread of k_msm_digits: a tile of 2^12 terms on 512 threads
 // Digits and coarse histograms in one launch (rounds 2-4: k_msm_digits over the terms, then k_msm_count1 over (tile, window) re-reading the digits).  Block = one tile
 // of 2^lgTile terms (tiles never span two sums): a thread converts its eight terms once, writes their W digits (coalesced per window) and counts each in the LDS
 // histogram of its window - W x CB counters, dynamic LDS (17 x 128 for a 2^21-term sum).
@@ -93,23 +88,42 @@ __global__ void __launch_bounds__(512) k_msm_digits(MsmSegs S, MsmPlan P, uint32
     extern __shared__ uint32_t hist[];                       // [W][CB]
     if (blockIdx.x == 0 && threadIdx.x == 0) { *heavy_count = 0; *medium_count = 0; }     // lists of k_bucket_combine, filled later on this stream
     uint32_t m, t, g0, g1; msm_tile_of(P, blockIdx.x, m, t, g0, g1);
+    if (g1 <= g0) return;                                    // a sum without terms has one empty tile (its counters were zeroed by the host); the whole block leaves
     const uint32_t nh = P.W * P.CB;
     for (uint32_t b = threadIdx.x; b < nh; b += blockDim.x) hist[b] = 0;
     __syncthreads();
-    // 512 threads, eight terms each: the kernel is the terms' arithmetic (a Montgomery reduction and W digits) and wants every tile of a 2^21-term sum resident at
-    // once - 512 blocks, two per CU at four waves per SIMD (1,024 threads per block needed eight waves per SIMD, which its register count does not allow: the blocks
-    // ran in two rounds).  The counters are incremented without their values coming back (no slot is taken here: k_msm_scatter1 takes them), so lanes with one key
-    // cost a wave 64 cycles, not a round trip each
-    for (uint32_t g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
-        const uint32_t s = msm_find_seg(S, g), i = g - S.start[s];
+    // 512 threads, eight terms each (a tile is 2^12 terms).  The terms are converted first and kept in registers (8 x 8 words); then the WINDOWS are the outer loop:
+    // a window's bit offset is the wave's (one scalar load per window - with the terms outside, every digit of every term waited for two of them, and a launch
+    // of ten blocks took as long as one of five hundred: 75 us), its eight digits are stored (coalesced per window) and counted.  The counters are incremented
+    // without their values coming back (no slot is taken here: k_msm_scatter1 takes them), so lanes with one key cost a wave 64 cycles, not a round trip each
+    uint32_t w[MSM_DIG_PER][8];
+    uint32_t livemask = 0, inmask = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < MSM_DIG_PER; u++) {
+        const uint32_t g = g0 + u * 512u + threadIdx.x;
+        const bool in = g < g1;
+        const uint32_t gg = in ? g : g0;
+        const uint32_t s = msm_find_seg(S, gg), i = gg - S.start[s];
         const uint32_t *skip = S.skip[s];
-        const bool live = !(skip && ((skip[i >> 5] >> (i & 31u)) & 1u));            // a skipped term was merged away (its scalar rides on another term of this sum): no entry in any window
-        uint32_t w[8]; msm_biased_words(w, S.sc[s][i], P);
-        for (uint32_t j = 0; j < P.W; j++) {
-            const uint32_t d = live ? (uint32_t)(msm_digit_biased(w, P.W, j) + 32768) : 32768u;
-            dig[(size_t)j * total + g] = (uint16_t)d;
+        const bool live = in && !(skip && ((skip[i >> 5] >> (i & 31u)) & 1u));       // a skipped term was merged away (its scalar rides on another term of this sum): no entry in any window
+        msm_biased_words(w[u], S.sc[s][i], P);
+        if (in) inmask |= 1u << u;
+        if (live) livemask |= 1u << u;
+    }
+    for (uint32_t j = 0; j < P.W; j++) {
+        const uint32_t off = P.off[j], wd = P.off[j + 1] - off, wi = off >> 5, sh = off & 31u, half = 1u << (wd - 1u), mask = (1u << wd) - 1u;
+        uint32_t *hj = hist + j * P.CB;
+        uint16_t *dj = dig + (size_t)j * total + g0 + threadIdx.x;
+#pragma unroll
+        for (uint32_t u = 0; u < MSM_DIG_PER; u++) {
+            uint32_t lo = w[u][0], hi = w[u][1];                                     // words wi, wi + 1 of the term (wi is the wave's: a chain of scalar compares, no indexed registers)
+#pragma unroll
+            for (uint32_t k = 1; k < 8; k++) { if (wi == k) { lo = w[u][k]; hi = k < 7 ? w[u][k + 1] : 0u; } }
+            const uint64_t two = (uint64_t)lo | ((uint64_t)hi << 32);
+            const uint32_t d = ((livemask >> u) & 1u) ? (((uint32_t)(two >> sh) & mask) - half + 32768u) : 32768u;
+            if ((inmask >> u) & 1u) dj[u * 512u] = (uint16_t)d;
             const uint32_t mag = msm_dig_mag(d);
-            if (mag) atomicAdd(&hist[j * P.CB + ((mag - 1u) >> P.fb)], 1u);
+            if (mag) atomicAdd(&hj[(mag - 1u) >> P.fb], 1u);
         }
     }
     __syncthreads();
