@@ -78,6 +78,8 @@ def parse_args(argv=None):
                     "prover, 51.5 GB of fold tables per device) or oneshot (what a bare bpg_ctx_create gives a drop-in caller: 3 GB of tables)")
     ap.add_argument("--plan-only", action="store_true", help="print what --gpus N would do on this node - per rank: device, NUMA node, CPU set, chain-pool lanes, expected HBM and "
                     "pinned host memory - from the planner the real run uses, WITHOUT touching a GPU; a node with fewer cards is planned on an assumed 2-socket topology")
+    ap.add_argument("--lone-proof", action="store_true", help="with --headline-only: also prove once ALONE on the device after the timed steps and report `lone_proof` "
+                    "(phase times of the library clock, sum of the kernels' HIP-event durations, launches) - what the one-shot child of the default run adds to `value_one_shot`")
     ap.add_argument("--no-one-shot-leg", action="store_true", help="skip `value_one_shot` (the timed steps once more under the one-shot profile, in a child process)")
     return ap.parse_args(argv)
 
@@ -567,7 +569,7 @@ def one_shot_leg(args):
     """`value_one_shot`: the SAME K timed steps (same command, streams, chain pool, seeds) with every context under the ONE-SHOT profile - what a
     drop-in caller of bpg_ctx_create(device) gets: first fold on width-5 NAF tables of scalars cut in two (3.0 GB at 2^20), no 8-bit tail tables.  Run as
     a child process: tables are per process and device, and the serving tables this process holds would count against the one-shot budget."""
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--headline-only", "--profile", "oneshot", "--no-one-shot-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--headline-only", "--lone-proof", "--profile", "oneshot", "--no-one-shot-leg", "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--leaves", str(args.leaves), "--streams", str(args.streams), "--chain-workers", str(args.chain_workers), "--chain-lanes", str(args.chain_lanes),
            "--chain-pool", args.chain_pool]
     env = dict(os.environ)
@@ -592,6 +594,7 @@ def one_shot_leg(args):
                         "parent (this serving run, idle meanwhile) held when it started the child")
     return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"], "hbm_in_use": hbm,
             "completions": d.get("completions"), "schedule": d.get("schedule"), "busy_cores_avg": d["config"]["host_threads_per_gpu"]["busy_cores_avg"],
+            "lone_proof": d.get("lone_proof"),
             "note": "the same timed steps with every engine context under the one-shot profile (bpg_ctx_create's default; blocking stream waits as in the headline), "
                     "in a child process of this run while this process idles; `value` of the line is the serving profile"}
 
@@ -905,7 +908,8 @@ def run_rank(args):
     tm = kernels = None
     latency_ms = None
     gpu_ms_per_proof = None
-    if not args.headline_only:
+    lone_proof = None
+    if not args.headline_only or args.lone_proof:
         # one proof alone, its chain drawn inside the call (what a single cold request costs), with phase timings
         t0 = time.perf_counter()
         alone = res.prove(state, inst.v_blinding, seed_for(0), 0, timings=True)
@@ -917,6 +921,11 @@ def run_rank(args):
         res.prove(state, inst.v_blinding, seed_for(5001), 0)
         kernels = collect_profile()
         gpu_ms_per_proof = sum(v["total_ms"] for v in kernels.values())
+        kern_only = {k: v for k, v in kernels.items() if not k.startswith("_")}
+        lone_proof = {"profile": args.profile, "phase_ms": tm, "wall_ms": latency_ms, "kernel_ms_sum": sum(v["total_ms"] for v in kern_only.values()),
+                      "launches": int(sum(v["count"] for v in kern_only.values())),
+                      "note": "one 2^20 proof ALONE on the device, its chain drawn inside the call: phase times of the library's clock (rng_host = the 0.30 s chain, under "
+                              "which A_I, A_O and most of S run), the sum of the HIP-event durations of every kernel of another lone proof, and the launches of that proof"}
 
     single, prof_isolated = None, None
     if not args.headline_only and prefetch and args.chain_workers > 1:
@@ -1124,7 +1133,7 @@ def run_rank(args):
                       "proving_streams_per_gpu": n_streams,
                       "backend": backend if world > 1 else None},
            "roofline": roofline, "ranks_seen": ranks_seen, "host": dict(host_description(), placement=placement),
-           "single_stream": single, "one_host_thread": one_thread, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "verify": verify_info, "expanded_blinding": expanded,
+           "single_stream": single, "one_host_thread": one_thread, "single_proof_latency_ms": latency_ms, "phase_ms": tm, "lone_proof": lone_proof, "verify": verify_info, "expanded_blinding": expanded,
            "setup_s": {"assembly_and_commit": t_asm, "generators": t_gens, "upload": t_up}, "source_hash": src, "schedule": schedule, "profile": args.profile}
     if completions is not None:
         out["completions"] = completions

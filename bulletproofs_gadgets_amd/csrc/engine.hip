@@ -234,7 +234,7 @@ struct Engine::Impl {
     double prof_ms[KID_COUNT] = {0};
     uint64_t prof_count[KID_COUNT] = {0};
     double prof_alg_bytes[KID_COUNT] = {0}, prof_act_bytes[KID_COUNT] = {0}, prof_fm[KID_COUNT] = {0};
-    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_bucket_chunks)); }
+    bool prof_on(int id) const { return prof_mode == 2 || (prof_mode == 1 && (id == KID_k_fold_points || id == KID_k_fold_points_reg || id == KID_k_fold_points_split || id == KID_k_fold_points_wnaf || id == KID_k_fold_points_quad || id == KID_k_fold_points_quadw || id == KID_k_fold_points_regw || id == KID_k_bucket_chunks)); }
     hipEvent_t prof_event() { if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; } hipEvent_t e; HIPCHK(hipEventCreate(&e)); return e; }
     void prof_begin(int id) { if (!prof_on(id)) return; ProfRec r{id, prof_event(), prof_event()}; HIPCHK(hipEventRecord(r.a, st)); prof_open.push_back(r); }
     void prof_end(int id) { if (!prof_on(id)) return; HIPCHK(hipEventRecord(prof_open.back().b, st)); }
@@ -911,7 +911,7 @@ Engine::Impl::MsmTicket Engine::Impl::msm(const MsmSegs &S, uint32_t nmsm) {
         if (cc - 1 > (int)fbmax + 9) cc = (int)fbmax + 10;
         fb = std::min<uint32_t>(fbmax, (uint32_t)cc - 1);
     }
-    // W near-equal windows over 254 bits (kernels.cuh msm_off); the widest has cmax bits -> 2^(cmax-1) buckets per window
+    // W near-equal windows over 254 bits (window j starts at bit j * 254 / W: MsmPlan::off); the widest has cmax bits -> 2^(cmax-1) buckets per window
     const uint32_t W = (254 + (uint32_t)cc - 1) / (uint32_t)cc, cmax = (254 + W - 1) / W, nb = 1u << (cmax - 1);
     if (fb > cmax - 1) fb = cmax - 1;
     const uint32_t nkeys = nmsm * W * nb;
@@ -1227,6 +1227,7 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
     const scm w_m = to_scm(w), uch_m = to_scm(u_ch);
     uint64_t mcur = N;
     // table-driven tail state (kernels.cuh "table-driven IPA tail")
+    const uint32_t quad_sums = I.shared_now ? 0u : 1u;                 // the block sums of the tail kernels: quad layout for a proof alone (k_points.cuh ge_block_sum_store)
     bool tt_on = false; uint32_t tt_j = 0, tt_lgM0 = 0, tt_cur = 0; Scalar tt_u, tt_uinv; const ge_pniels *tt_wide = nullptr;
     // grouped-fold state
     const uint32_t GRP_STRIDE = 64;
@@ -1253,11 +1254,11 @@ void Engine::Impl::inner_product(Transcript &T, std::vector<uint8_t> &proof, uin
                 tt_cur ^= 1u; std::swap(c0, c1);
             }
             const uint32_t nblk = cdiv((uint64_t)M0 * 8, 256);
-            if (tt_wide) BPG_LAUNCH(I, k_tt_round8, dim3(nblk, 2), dim3(256), tt_wide, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j, I.tt_partial.as<ge_ext>());
+            if (tt_wide) BPG_LAUNCH(I, k_tt_round8, dim3(nblk, 2), dim3(256), tt_wide, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j, I.tt_partial.as<ge_ext>(), quad_sums);
             else BPG_LAUNCH(I, k_tt_round, dim3(nblk, 2), dim3(256), I.tt_table_p, a, b, I.tt_f.as<scm>(), I.tt_f.as<scm>() + M0, c0, tt_lgM0, tt_j,
-                       I.tt_partial.as<ge_ext>());
+                       I.tt_partial.as<ge_ext>(), quad_sums);
             BPG_LAUNCH(I, k_tt_finish, dim3(2), dim3(256), I.tt_partial.as<ge_ext>(), nblk, a, b, (uint32_t)h, w_m,
-                       I.tt_table_p + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
+                       I.tt_table_p + (size_t)2 * M0 * TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>(), quad_sums);
             HIPCHK(hipGetLastError());
             uint8_t lr[64];
             uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);       // L, R as extended points; encoded on the host
@@ -1763,9 +1764,9 @@ std::vector<uint8_t> Engine::prove(DeviceCircuit *c, Transcript &T, const std::v
     if (tabled) {
         const uint32_t M0 = (uint32_t)N, nblk = cdiv((uint64_t)M0 * 16, 256);
         BPG_LAUNCH(I, k_tt_commit3, dim3(nblk, 3), dim3(256), I.tt_table_p, c->aL.as<scm>(), c->aR.as<scm>(), c->aO.as<scm>(), sL, sR,
-                   (uint32_t)n, M0, I.tt_partial.as<ge_ext>());
+                   (uint32_t)n, M0, I.tt_partial.as<ge_ext>(), I.shared_now ? 0u : 1u);
         BPG_LAUNCH(I, k_tt_commit3_finish, dim3(3), dim3(256), I.tt_partial.as<ge_ext>(), nblk, I.extras.as<scm>(),
-                   I.ped_table.as<ge_pniels>() + (size_t)TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>());
+                   I.ped_table.as<ge_pniels>() + (size_t)TT_WINDOWS * TT_MULTS, I.msm_result.as<ge_ext>(), I.shared_now ? 0u : 1u);
         HIPCHK(hipGetLastError());
         uint32_t *hp = reinterpret_cast<uint32_t *>(I.h_small.as<uint8_t>() + 16384);           // three extended points; encoded on the host
         HIPCHK(hipMemcpyAsync(hp, I.msm_result.p, 3 * sizeof(ge_ext), hipMemcpyDeviceToHost, st));

@@ -168,7 +168,7 @@ __device__ __forceinline__ void tt_biased_words(uint32_t w[8], const scm &s) {
 // sub-round j of the tail (h = M0 >> (j+1)): blockIdx.y = 0 accumulates L, 1 accumulates R; thread = (base point, 8 windows)
 __global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ table, const scm *__restrict__ a, const scm *__restrict__ b,
                                                   const scm *__restrict__ fG, const scm *__restrict__ fH, const scm *__restrict__ c,
-                                                  uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */) {
+                                                  uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */, uint32_t quad) {
     __shared__ ge_ext lds[256];
     const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M0 = 1u << lgM0, e = tid >> 3, g = tid & 7u;
@@ -195,8 +195,7 @@ __global__ void __launch_bounds__(256) k_tt_round(const ge_pniels *__restrict__ 
             acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
         }
     }
-    const fe sum = ge_block_sum_quad(acc, lds);
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
+    ge_block_sum_store(acc, lds, quad, partial + cls * gridDim.x + blockIdx.x);
 }
 // Wide tables for a tail that starts on the ORIGINAL generators (circuits up to 2^14 multipliers freeze at round 0): those never change, so a
 // table of k * 2^(8w) * P (w < 32 windows of 8 bits, k = 1..128, 512 KB per point, built once per device) halves the additions of every round:
@@ -242,7 +241,7 @@ __device__ __forceinline__ void tt8_biased_words(uint32_t w[8], const scm &s) {
 }
 __global__ void __launch_bounds__(256) k_tt_round8(const ge_pniels *__restrict__ table, const scm *__restrict__ a, const scm *__restrict__ b,
                                                    const scm *__restrict__ fG, const scm *__restrict__ fH, const scm *__restrict__ c,
-                                                   uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */) {
+                                                   uint32_t lgM0, uint32_t j, ge_ext *__restrict__ partial /* [2][gridDim.x] */, uint32_t quad) {
     __shared__ ge_ext lds[256];
     const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t M0 = 1u << lgM0, e = tid >> 3, g = tid & 7u;
@@ -269,15 +268,14 @@ __global__ void __launch_bounds__(256) k_tt_round8(const ge_pniels *__restrict__
             acc = ge_add_pniels_signed(acc, tbl[k * TT8_MULTS + mag - 1], neg);
         }
     }
-    const fe sum = ge_block_sum_quad(acc, lds);
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
+    ge_block_sum_store(acc, lds, quad, partial + cls * gridDim.x + blockIdx.x);
 }
 // A_I, A_O, S of a circuit whose generators already have window tables (N <= 2^14: the tables of the frozen IPA tail are those of
 // the original generators and live with the context): blockIdx.y = 0: <a_L,G> + <a_R,H>, 1: <a_O,G>, 2: <s_L,G> + <s_R,H>; same thread
 // layout as k_tt_round (8 threads per base point, 8 windows each), block partials to partial[3][gridDim.x].
 __global__ void __launch_bounds__(256) k_tt_commit3(const ge_pniels *__restrict__ table, const scm *__restrict__ aL, const scm *__restrict__ aR,
                                                     const scm *__restrict__ aO, const scm *__restrict__ sL, const scm *__restrict__ sR,
-                                                    uint32_t n, uint32_t M0, ge_ext *__restrict__ partial) {
+                                                    uint32_t n, uint32_t M0, ge_ext *__restrict__ partial, uint32_t quad) {
     __shared__ ge_ext lds[256];
     const uint32_t cls = blockIdx.y, tid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t e = tid >> 3, g = tid & 7u;
@@ -297,12 +295,11 @@ __global__ void __launch_bounds__(256) k_tt_commit3(const ge_pniels *__restrict_
             acc = ge_add_pniels_signed(acc, tbl[k * TT_MULTS + mag - 1], neg);
         }
     }
-    const fe sum = ge_block_sum_quad(acc, lds);
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(partial + cls * gridDim.x + blockIdx.x)[threadIdx.x] = sum;
+    ge_block_sum_store(acc, lds, quad, partial + cls * gridDim.x + blockIdx.x);
 }
 // block k: out[k] = sum of partial[k][0..nblk) + blind[k] * (fixed base whose window table is tableX)
 __global__ void __launch_bounds__(256) k_tt_commit3_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ blind,
-                                                           const ge_pniels *__restrict__ tableX, ge_ext *__restrict__ out) {
+                                                           const ge_pniels *__restrict__ tableX, ge_ext *__restrict__ out, uint32_t quad) {
     __shared__ ge_ext lds[256];
     const uint32_t cls = blockIdx.x;
     ge_ext acc = ge_identity();                              // as in k_tt_finish: first point as it is, the blinding term on the last threads
@@ -319,12 +316,11 @@ __global__ void __launch_bounds__(256) k_tt_commit3_finish(const ge_ext *__restr
             acc = threadIdx.x >= nblk ? ge_from_pniels_signed(q, neg) : ge_add_pniels_signed(acc, q, neg);
         }
     }
-    const fe sum = ge_block_sum_quad(acc, lds);
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(out + cls)[threadIdx.x] = sum;
+    ge_block_sum_store(acc, lds, quad, out + cls);
 }
 // block 0 -> L, block 1 -> R: sum the block partials, add (c * w) * B with c = <a_lo, b_hi> resp. <a_hi, b_lo>; the point goes to the host, which encodes it
 __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ partial, uint32_t nblk, const scm *__restrict__ a, const scm *__restrict__ b,
-                                                   uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, ge_ext *__restrict__ out) {
+                                                   uint32_t h, scm wq, const ge_pniels *__restrict__ tableB, ge_ext *__restrict__ out, uint32_t quad) {
     __shared__ ge_ext lds[256];
     __shared__ scm slds[256];
     const uint32_t cls = blockIdx.x;
@@ -347,8 +343,7 @@ __global__ void __launch_bounds__(256) k_tt_finish(const ge_ext *__restrict__ pa
             acc = threadIdx.x >= nblk ? ge_from_pniels_signed(q, neg) : ge_add_pniels_signed(acc, q, neg);
         }
     }
-    const fe sum = ge_block_sum_quad(acc, lds);
-    if (threadIdx.x < 4) reinterpret_cast<fe *>(out + cls)[threadIdx.x] = sum;
+    ge_block_sum_store(acc, lds, quad, out + cls);
 }
 
 // Pedersen commitments v*B + r*B_blinding from the window tables of the two fixed bases (k_tt_bases / k_tt_multiples on

@@ -4,10 +4,9 @@
 namespace bpg {
 
 // ------------------------------------------------------------------------------------------------ multiscalar multiplication
-// Window j of W covers bits [off(j), off(j+1)) with off(j) = j*254/W: near-equal widths, so that the top window keeps
+// Window j of W covers bits [off(j), off(j+1)) with off(j) = j*254/W (MsmPlan::off, filled by the host): near-equal widths, so that the top window keeps
 // (almost) a full width of entropy - with fixed c-bit windows the last one holds only 253 mod c bits and a handful of
 // buckets would receive every term.  Signed digits: digit j in (-2^(wd-1), 2^(wd-1)], wd = width of window j.
-__device__ __forceinline__ uint32_t msm_off(uint32_t j, uint32_t W) { return (j * 254u) / W; }
 __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
     uint32_t s = 0;
 #pragma unroll
@@ -22,7 +21,7 @@ __device__ __forceinline__ uint32_t msm_find_seg(const MsmSegs &S, uint32_t g) {
 // field_j(s + bias) - 2^(wd(j)-1), in [-2^(wd-1), 2^(wd-1)).
 struct MsmPlan {
     uint32_t nmsm, W, nb, lgTile, tmax;
-    uint8_t off[132];            // off[j] = first bit of window j, j <= W (msm_off; the host fills it: a division by W per digit was two thirds of k_msm_digits' instructions)
+    uint8_t off[132];            // off[j] = j * 254 / W, the first bit of window j, j <= W (the host fills it: the kernel divided by W twice per digit)
     uint32_t fb, CB;             // two-level sort: a bucket index splits into CB coarse bins x 2^fb fine slots (nb = CB << fb)
     uint32_t term_start[5];      // first global term of MSM m (term_start[nmsm] = total)
     uint32_t tile_start[5];      // first tile of MSM m
