@@ -14,8 +14,10 @@
 #          (tools/diag/mask_build.sh must have built tools/diag/libbpg_hip_mask.so in the build container) -> <tag>_mask_ab.txt
 #   clock  shader clock and board power while the mix / one stream runs (tools/diag/clock_watch.py) -> <tag>_clock.txt
 #   appetite  value / HBM / busy cores for {serving, one-shot} x {20, 10, 6} streams (tools/diag/appetite.sh) -> <tag>_appetite.txt
+#   lone   one 2^20 proof ALONE on the device under both profiles and both kinds of stream wait (tools/diag/lone_proof.sh) -> <tag>_lone_proof.txt
 #   inv    what a field inversion and a mixed addition cost in field multiplications (tools/diag/bench_inv.hip): the constants behind "no batched-affine sweep" -> <tag>_inversion_cost.json
-# The sanitizer evidence (profiles/<tag>_sanitizers.txt) is taken in the BUILD container, last, by tools/sanitize_round.sh <tag>, which fails when its source
+# Back in the build container: python tools/collect_round.py <tag> copies the files into profiles/ (and refuses evidence of other sources); then
+# the sanitizer evidence (profiles/<tag>_sanitizers.txt) is taken in the BUILD container, last, by tools/sanitize_round.sh <tag>, which fails when its source
 # hash differs from the one in the counter files this script wrote.
 # rocprofv3 gets the program itself after "--" (python3 bench.py ... or the calibration binary), never a shell or env wrapper.
 set -o pipefail
@@ -93,6 +95,10 @@ if has clock; then
     python3 "$root/tools/diag/clock_watch.py" "mix (6 proving streams)" -- python3 "$root/bench.py" --in-flight-only --in-flight-steps 48 > "$out/${tag}_clock.txt" 2> "$out/${tag}_clock.err" || true
     python3 "$root/tools/diag/clock_watch.py" "one stream" -- python3 "$root/bench.py" --headline-only --streams 1 --chain-workers 1 --steps 5 --warmup 2 >> "$out/${tag}_clock.txt" 2>> "$out/${tag}_clock.err" || true
     echo "clock done"
+fi
+if has lone; then
+    bash "$root/tools/diag/lone_proof.sh" > "$out/${tag}_lone_proof.txt" 2>&1 || true
+    echo "lone done"
 fi
 if has appetite; then
     bash "$root/tools/diag/appetite.sh" > "$out/${tag}_appetite.txt" 2>&1 || true
