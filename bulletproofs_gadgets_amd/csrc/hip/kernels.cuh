@@ -2,16 +2,18 @@
 // no MFMA - this is 255-bit modular arithmetic, not a dense contraction.  Hot-path rows of SURVEY.md section 8(a):
 //   a7  BulletproofGens::new            k_gens_derive + k_normalize_niels
 //   a1-a3,a6  Pedersen commits          k_pedersen (window tables of B and B_blinding: k_tt_bases, k_tt_multiples)
-//   a9  A_I, A_O, S multiscalar muls    k_msm_digits, k_scan_*, k_msm_scatter1, k_msm_sort2 (two-level sort), k_bucket_chunks,
-//                                       k_bucket_combine(_per_bucket, _heavy), k_bucket_reduce, k_window_sums
+//   a9  A_I, A_O, S multiscalar muls    k_msm_digits (digits + coarse counts), k_scan_blocksums / _apply, k_msm_scatter1, k_msm_sort2 (two-level sort), k_bucket_chunks,
+//                                       k_bucket_combine(_per_bucket, _heavy), k_bucket_reduce, k_window_sums (a shared device) / k_window_sums_quad (a proof alone)
 //                                       (bucket method: digits -> coarse partition in LDS -> fine counting sort -> balanced bucket sweep -> reductions;
 //                                       the 17 window sums are recombined and encoded on the host, host/fe51.hpp)
 //       equal scalars of a_L, a_R        k_merge_insert, k_merge_flags, k_merge_members, k_merge_sum (k_merge.cuh): terms of A_I that carry the same value share one
 //                                       bucket entry per window on the sum of their generators; once per uploaded witness
 //   a10 vector-polynomial phase         k_exp_table, k_flatten, k_poly_t, k_poly_eval, k_reduce_partials
-//   a11 inner-product argument          above 2^14 generators: k_ipa_prep, the MSM kernels, k_tt_advance, one generator fold per group of rounds -
+//   a11 inner-product argument          above 2^12 generators (a circuit of N <= 2^14: none): k_ipa_prep, the MSM kernels, k_tt_advance, one generator fold per group of rounds -
 //                                       k_fold_points_wnaf on the original generators (tables of (2m+1) * 2^(64j) * P: k_odd_start(_ext), k_odd_step,
-//                                       k_dbl_times), k_fold_points_quad / _split / _reg<NT> / k_fold_points on folded ones; below: k_tt_bases,
+//                                       k_dbl_times); on folded ones k_fold_points_quadw (a proof alone) / k_fold_points_regw (a shared device): width-4 NAF
+//                                       steps against multiples the kernel makes itself - and k_fold_points_quad / _split / _reg<NT> / k_fold_points for the
+//                                       shapes those two do not take (first groups, outputs that do not fill whole blocks); below: k_tt_bases,
 //                                       k_tt_multiples, k_tt_factors, then k_tt_advance, k_tt_round, k_tt_finish per round
 //   f1  Verifier::verify                k_decompress, k_flatten_const, k_ipa_s, k_verify_scalars + one MSM
 // The kernels live in k_points.cuh, k_scalars.cuh, k_ipa.cuh, k_verify.cuh and k_msm.cuh, included at the end of this file in that order.
