@@ -71,11 +71,13 @@ def parse_tree(text):
     pos = 0
     inst, wit = [], []
 
-    def node():
+    def node(depth=0):
         nonlocal pos
+        if depth > 64 or pos >= len(toks):      # nesting bounded like the native driver and the library (Pattern::MAX_DEPTH)
+            raise ValueError("malformed tree")
         t = toks[pos]; pos += 1
         if t == "(":
-            l = node(); r = node()
+            l = node(depth + 1); r = node(depth + 1)
             if pos >= len(toks) or toks[pos] != ")":
                 raise ValueError("malformed tree")
             pos += 1

@@ -193,10 +193,11 @@ Tree parse_tree(const std::string &text) {
     }
     Tree t; size_t pos = 0;
     struct Rec { std::vector<std::string> &toks; size_t &pos; Tree &t;
-        std::string node() {
+        std::string node(unsigned depth = 0) {
+            if (depth > 64) fail("malformed tree: nested deeper than 64 levels");      // the recursion is bounded by the INPUT otherwise (fuzzer: stack overflow on ten thousand brackets)
             if (pos >= toks.size()) fail("malformed tree");
             std::string k = toks[pos++];
-            if (k == "(") { std::string l = node(), r = node(); if (pos >= toks.size() || toks[pos] != ")") fail("malformed tree"); pos++; return "(" + l + " " + r + ")"; }
+            if (k == "(") { std::string l = node(depth + 1), r = node(depth + 1); if (pos >= toks.size() || toks[pos] != ")") fail("malformed tree"); pos++; return "(" + l + " " + r + ")"; }
             if (k[0] == 'W') { t.wit.push_back(k); return "W"; }
             if (k[0] == 'I') { t.inst.push_back(k); return "I"; }
             fail("malformed tree");

@@ -179,17 +179,21 @@ struct Pattern {
     static std::shared_ptr<Pattern> leaf(Kind k) { auto p = std::make_shared<Pattern>(); p->kind = k; return p; }
     static std::shared_ptr<Pattern> hash(std::shared_ptr<Pattern> l, std::shared_ptr<Pattern> r) { auto p = std::make_shared<Pattern>(); p->kind = Hash; p->left = l; p->right = r; return p; }
     // textual form "(W (I W))" with W / I leaves, as in the .gadgets tree syntax (gadget_grammar.lalrpop:54-79)
-    static std::shared_ptr<Pattern> parse(const std::string &s) { size_t pos = 0; auto p = parse_at(s, pos); skip(s, pos); if (pos != s.size()) throw std::invalid_argument("pattern: trailing input"); return p; }
+    // Nesting is bounded (MAX_DEPTH levels: a path through 2^64 leaves is no tree anybody proves): the parser, the assembly and the destructor recurse once per
+    // level, and the text comes from a file - ten thousand opening brackets were a stack overflow (found by the fuzzer of tests/hostcheck, round 5).
+    static constexpr uint32_t MAX_DEPTH = 64;
+    static std::shared_ptr<Pattern> parse(const std::string &s) { size_t pos = 0; auto p = parse_at(s, pos, 0); skip(s, pos); if (pos != s.size()) throw std::invalid_argument("pattern: trailing input"); return p; }
 private:
     static void skip(const std::string &s, size_t &pos) { while (pos < s.size() && (s[pos] == ' ' || s[pos] == '\t')) pos++; }
-    static std::shared_ptr<Pattern> parse_at(const std::string &s, size_t &pos) {
+    static std::shared_ptr<Pattern> parse_at(const std::string &s, size_t &pos, uint32_t depth) {
+        if (depth > MAX_DEPTH) throw std::invalid_argument("pattern: nested deeper than 64 levels");
         skip(s, pos);
         if (pos >= s.size()) throw std::invalid_argument("pattern: unexpected end");
         if (s[pos] == 'W') { pos++; return leaf(W); }
         if (s[pos] == 'I') { pos++; return leaf(I); }
         if (s[pos] != '(') throw std::invalid_argument("pattern: expected '(', 'W' or 'I'");
         pos++;
-        auto l = parse_at(s, pos); auto r = parse_at(s, pos);
+        auto l = parse_at(s, pos, depth + 1); auto r = parse_at(s, pos, depth + 1);
         skip(s, pos);
         if (pos >= s.size() || s[pos] != ')') throw std::invalid_argument("pattern: expected ')'");
         pos++;

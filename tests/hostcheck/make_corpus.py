@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Seed corpus of tests/hostcheck/fuzz_cli: one file per stem of tests/golden/resources (the reference's own test inputs) in the target's
 five-section form (gadgets, inst, wtns, coms, proof separated by "===="), with plausible .coms / .proof sections so that the verifier side
-gets past its first reads; plus a few hand-made edge cases (empty files, unknown gadget, unbalanced OR block, odd hex, long values)."""
+gets past its first reads; plus a few hand-made edge cases (empty files, unknown gadget, unbalanced OR block, odd hex, long values, a tree of twenty thousand opening brackets)."""
 import hashlib, pathlib, sys
 out = pathlib.Path(sys.argv[1]); out.mkdir(parents=True, exist_ok=True)
 res = pathlib.Path(__file__).resolve().parent.parent / "golden" / "resources"
@@ -30,6 +30,7 @@ edge = {
     "open_or": "OR [\n{\nBOUND W0 I0 I1\n" + SEP + "I0 = 0x00\nI1 = 0xff\n" + SEP + "W0 = 0x05\n" + SEP + SEP,
     "odd_hex": "BOUND W0 I0 I1\n" + SEP + "I0 = 0x0\nI1 = 0xfff\n" + SEP + "W0 = 0x5\n" + SEP + SEP,
     "long_bound": "BOUND W0 I0 I1\n" + SEP + "I0 = 0x00\nI1 = 0x" + "ff" * 40 + "\n" + SEP + "W0 = 0x" + "05" * 70 + "\n" + SEP + SEP,
+    "tree_deep": "MERKLE I0 " + "(" * 20000 + "W0" + "\n" + SEP + "I0 = 0x01\n" + SEP + "W0 = 0x03\n" + SEP + SEP,
     "tree_garbage": "MERKLE I0 ((W0 I1) (W1\n" + SEP + "I0 = 0x01\nI1 = 0x02\n" + SEP + "W0 = 0x03\nW1 = 0x04\n" + SEP + SEP,
     "set_member": "SET_MEMBER W0 I0 W1 I1\n" + SEP + "I0 = 0x" + "aa" * 40 + "\nI1 = 0x07\n" + SEP + "W0 = 0x07\nW1 = 0x" + "bb" * 33 + "\n" + SEP + SEP,
 }

@@ -17,6 +17,13 @@ def test_tree_parser():
     assert cli.parse_tree("(((W2 W3) I0) W9)")[2] == "(((W W) I) W)"
     with pytest.raises(ValueError):
         cli.parse_tree("(W0 I1")
+    # nesting is bounded - 64 levels in both drivers and in the library (Pattern::MAX_DEPTH): twenty thousand opening brackets were a stack overflow of the
+    # native driver under the fuzzer (tests/hostcheck), a RecursionError here
+    deep = lambda d: "(" * d + "W0" + " I1)" * d
+    assert cli.parse_tree(deep(60))[2].count("(") == 60
+    for bad in (deep(80), "(" * 20000 + "W0"):
+        with pytest.raises(ValueError):
+            cli.parse_tree(bad)
     assert cli.round_pow2(14988) == 16384 and cli.round_pow2(128) == 128 and cli.round_pow2(1) == 1
 
 

@@ -136,6 +136,12 @@ def test_merkle_assembly_sizes_and_witness_synthesis(golden):
         bpg.MerkleTree256(root4, [leaf] * 3, [], "((I I) (I I))").prove(bpg.Prover(None, bpg.Transcript(b"x")), [], [])
     with pytest.raises(bpg.BpgError):
         bpg.MerkleTree256(root4, [], [], "((I I) (I")
+    # nesting is bounded (Pattern::MAX_DEPTH = 64: parser, assembly and destructor recurse once per level, and the text comes from a file): a pattern of
+    # twenty thousand opening brackets is INVALID_ARGUMENT, not a stack overflow across the C ABI
+    for bad in ("(" * 20000 + "I", "(" * 70 + "I" + " I)" * 70):
+        with pytest.raises(bpg.BpgError):
+            bpg.MerkleTree256(root4, [leaf] * 80, [], bad)
+    bpg.MerkleTree256(root4, [leaf] * 61, [], "(" * 60 + "I" + " I)" * 60)       # sixty levels are a tree
 
 
 def test_verifier_side_gadget_sizes():
