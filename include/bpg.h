@@ -285,6 +285,7 @@ bpg_status bpg_verifier_verify(bpg_verifier *v, bpg_ctx *ctx, uint64_t gens_capa
 
 bpg_status bpg_bounds_check_new(const uint8_t *min_be, uint64_t min_len, const uint8_t *max_be, uint64_t max_len, bpg_gadget **out);
 bpg_status bpg_mimc_hash256_new(const bpg_lc *image, bpg_gadget **out);
+/* pattern: the tree syntax of the .gadgets grammar with W / I leaves, e.g. "((W I) (I W))"; at most 64 levels of nesting (BPG_ERR_INVALID_ARGUMENT beyond) */
 bpg_status bpg_merkle_tree256_new(const bpg_lc *root, const bpg_lc *instance_vars, uint64_t n_inst, const bpg_lc *witness_vars,
                                   uint64_t n_wit, const char *pattern, bpg_gadget **out);
 /* the remaining gadgets of the reference; assignment pointers may be NULL on the verifier side */
