@@ -191,18 +191,38 @@ __global__ void __launch_bounds__(256) k_msm_scatter1(MsmSegs S, MsmPlan P, cons
 // block per coarse bin k = (msm*W + window)*CB + bin: its entries are entries1[starts1[k*tmax], starts1[(k+1)*tmax]) (the last bin ends at
 // the grand total).  Counting sort by the fine bits; the bin's range of `entries` is written by this block alone.
 #define MSM_STASH 16384
+#define SORT2_PER 36                    // entries per thread of a bin that k_msm_sort2 keeps in registers and stages in LDS (a power-of-two sum's 8,192-entry bins with room to spare)
 __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__restrict__ starts1, uint32_t nflat, const uint32_t *__restrict__ entries1,
                                                    uint32_t *__restrict__ starts, uint32_t *__restrict__ entries) {
     __shared__ uint32_t cnt[128];
     __shared__ uint32_t cur[128];
-    __shared__ uint16_t slot16[MSM_STASH];                   // the slot each entry took in its bucket (bins of up to MSM_STASH entries: one atomic pass)
+    // 36 KB shared by the two shapes of a bin: up to 256 x SORT2_PER entries - the SORTED bin, staged here and copied out with consecutive lanes writing
+    // consecutive addresses; a larger bin (up to MSM_STASH entries) - the 16-bit slot each entry took in its bucket, between the two passes over the coarse list
+    __shared__ uint32_t shbuf[256 * SORT2_PER];
+    uint16_t *const slot16 = reinterpret_cast<uint16_t *>(shbuf);
+    static_assert(2 * 256 * SORT2_PER >= MSM_STASH, "the slot stash must fit the staging buffer");
     const uint32_t k = blockIdx.x, K = gridDim.x, nf = 1u << P.fb;
     const uint32_t s0 = starts1[(size_t)k * P.tmax], s1 = k + 1 < K ? starts1[(size_t)(k + 1) * P.tmax] : starts1[nflat];
     const bool stash = s1 - s0 <= MSM_STASH;
     for (uint32_t f = threadIdx.x; f < nf; f += blockDim.x) cnt[f] = 0;
     __syncthreads();
     const uint32_t fsh = 31u - P.fb, fmask = nf - 1u;
-    // four independent loads per thread and trip: a bin is a short stream (8 K entries), its latency, not its bytes, sets the pace
+    // A bin of up to 256 x SORT2_PER entries is read ONCE - every load of a thread in flight together - and stays in registers with the slots its entries took;
+    // the sorted bin goes through LDS, so that the 4-byte stores of a wave fall into four sectors instead of sixty-four (rounds 2-5, first session: every entry
+    // its own sector of the bin's 32 KB range - the launch was bound by the L2's transaction rate, not by its atomics or its loads)
+    const bool inregs = s1 - s0 <= 256u * SORT2_PER;                     // block-uniform
+    uint32_t rv[SORT2_PER], rs[SORT2_PER / 2];
+    if (inregs) {
+#pragma unroll
+        for (uint32_t u = 0; u < SORT2_PER; u++) { const uint32_t e = s0 + u * 256u + threadIdx.x; rv[u] = e < s1 ? entries1[e] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < SORT2_PER; u++) {
+            const bool on = s0 + u * 256u + threadIdx.x < s1;
+            const uint32_t slot = msm_lds_take(cnt, on ? (rv[u] >> fsh) & fmask : 0u, on);
+            if (u & 1u) rs[u >> 1] |= slot << 16; else rs[u >> 1] = slot;
+        }
+    } else
+    // four independent loads per thread and trip
     for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
         uint32_t v[4];
 #pragma unroll
@@ -229,6 +249,18 @@ __global__ void __launch_bounds__(256) k_msm_sort2(MsmPlan P, const uint32_t *__
     }
     __syncthreads();
     const uint32_t idxbits = 27u - P.fb, imask = (1u << idxbits) - 1u;
+    if (inregs) {
+#pragma unroll
+        for (uint32_t u = 0; u < SORT2_PER; u++) {
+            if (s0 + u * 256u + threadIdx.x < s1) {
+                const uint32_t v = rv[u], f = (v >> fsh) & fmask, slot = (rs[u >> 1] >> (16u * (u & 1u))) & 0xffffu;
+                shbuf[cur[f] - s0 + slot] = (v & 0x80000000u) | (((v >> idxbits) & 15u) << 27) | (v & imask);
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < s1 - s0; j += 256u) entries[s0 + j] = shbuf[j];
+        return;
+    }
     for (uint32_t e0 = s0 + threadIdx.x; e0 < s1 + 63u; e0 += 4u * blockDim.x) {
         uint32_t vv[4];
 #pragma unroll
