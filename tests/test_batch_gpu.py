@@ -122,6 +122,10 @@ def test_bench_spawns_its_own_ranks(leaves, steps):
     assert out["unit"] == "constraints/s" and out["higher_is_better"] is True and out["vs_baseline"] is None and out["dtype"] == "u32"
     assert "workload" in out["config"] and out["completions"]["last_ms"] > 0 and "cpu_baseline" not in out
     assert out["throughput"]["ranks_failed"] == 0 and out["throughput"]["proofs_in_flight_per_gpu"] == 2 and out["throughput"]["value"] > 0
+    lone = out["lone_proof"]                                                   # rank 0's proof alone: the library's phase clock, its kernels' time, its launches
+    assert lone["profile"] == "serving" and lone["launches"] > 20 and 0 < lone["kernel_ms_sum"] < lone["wall_ms"] and lone["phase_ms"]["ipa"] > 0
+    if leaves == 512:
+        assert lone["launches"] <= 200, lone["launches"]                       # the round-4 review's bar for a 2^20 proof alone (198 since round 5)
 
 
 RCCL_WORKER = textwrap.dedent('''
